@@ -1,0 +1,620 @@
+// api.cpp — implementation of the C ABI declared in include/rt_mi355x.h.
+//
+// Host-side driver of the wavefront pipeline: it owns the HBM workspace, enqueues generate / extend / shade /
+// accumulate on the context's stream and never reads a queue length back while a batch is in flight.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "kernels.h"
+#include "rt_device.h"
+#include "rt_math.h"
+#include "scene_build.h"
+
+#define RT_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_error;
+
+int set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return set_error(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE, "%s: %s", #expr, \
+                             hipGetErrorString(e_));                                                       \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *ptr = nullptr;
+    size_t cap = 0; // elements
+    int ensure(size_t n) {
+        if (n <= cap) return RT_OK;
+        if (ptr) {
+            HIP_TRY(hipFree(ptr));
+            ptr = nullptr;
+            cap = 0;
+        }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+        cap = n;
+        return RT_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+enum KernelKind { K_GENERATE = 0, K_EXTEND = 1, K_SHADE = 2, K_ACCUMULATE = 3, K_KINDS = 4 };
+
+} // namespace
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    uint32_t flags = 0;
+    uint32_t max_blocks = 2048;
+    uint64_t max_paths = 1ull << 24;
+
+    // wavefront workspace
+    DevBuf<float4> ray_o, ray_d, hit, beta, radiance;
+    DevBuf<uint32_t> queue[2];
+    DevBuf<uint32_t> counts;
+    DevBuf<rt::ExtendCounters> counters;
+    DevBuf<float> accum;     // rt_render's device image
+    DevBuf<float> ray_stage; // rt_trace_closest's device copies
+    DevBuf<uint32_t> hit_stage;
+    uint32_t *host_counts = nullptr; // pinned
+    size_t host_counts_cap = 0;
+
+    // timing
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    struct Span {
+        int kind;
+        size_t a, b;
+    };
+    std::vector<Span> spans;
+    size_t ev_used = 0;
+};
+
+struct rt_scene {
+    int device = 0;
+    rt::SceneDev dev{};
+    void *blocks[8] = {};
+    int n_blocks = 0;
+    std::vector<uint32_t> prim_of_slot;
+    rt_scene_info info{};
+    bool need_uv = false;
+};
+
+namespace {
+
+int ensure_paths(rt_context *c, size_t n) {
+    if (int rc = c->ray_o.ensure(n)) return rc;
+    if (int rc = c->ray_d.ensure(n)) return rc;
+    if (int rc = c->hit.ensure(n)) return rc;
+    return RT_OK;
+}
+
+int ensure_render(rt_context *c, size_t n, uint32_t max_depth) {
+    if (int rc = ensure_paths(c, n)) return rc;
+    if (int rc = c->beta.ensure(n)) return rc;
+    if (int rc = c->radiance.ensure(n)) return rc;
+    if (int rc = c->queue[0].ensure(n)) return rc;
+    if (int rc = c->queue[1].ensure(n)) return rc;
+    if (int rc = c->counts.ensure((size_t)max_depth + 2)) return rc;
+    if (int rc = c->counters.ensure(1)) return rc;
+    return RT_OK;
+}
+
+int ensure_host_counts(rt_context *c, size_t n) {
+    if (n <= c->host_counts_cap) return RT_OK;
+    if (c->host_counts) HIP_TRY(hipHostFree(c->host_counts));
+    c->host_counts = nullptr;
+    c->host_counts_cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->host_counts), n * sizeof(uint32_t), hipHostMallocDefault));
+    c->host_counts_cap = n;
+    return RT_OK;
+}
+
+int timed_begin(rt_context *c, int kind) {
+    if (!(c->flags & RT_CTX_TIMING)) return RT_OK;
+    while (c->ev_pool.size() < c->ev_used + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(c->ev_pool[c->ev_used], c->stream));
+    c->spans.push_back({kind, c->ev_used, c->ev_used + 1});
+    return RT_OK;
+}
+
+int timed_end(rt_context *c) {
+    if (!(c->flags & RT_CTX_TIMING)) return RT_OK;
+    HIP_TRY(hipEventRecord(c->ev_pool[c->ev_used + 1], c->stream));
+    c->ev_used += 2;
+    return RT_OK;
+}
+
+int collect_timing(rt_context *c, rt_stats *st) {
+    if (!(c->flags & RT_CTX_TIMING)) return RT_OK;
+    double sums[K_KINDS] = {0, 0, 0, 0};
+    for (const auto &s : c->spans) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[s.a], c->ev_pool[s.b]));
+        sums[s.kind] += ms;
+    }
+    st->generate_ms = sums[K_GENERATE];
+    st->extend_ms = sums[K_EXTEND];
+    st->shade_ms = sums[K_SHADE];
+    st->accumulate_ms = sums[K_ACCUMULATE];
+    return RT_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **dst, uint64_t &bytes) {
+    *dst = nullptr;
+    size_t n = v.size() ? v.size() : 1;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+    s->blocks[s->n_blocks++] = p;
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(p);
+    bytes += n * sizeof(T);
+    return RT_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------
+RT_API const char *rt_last_error(void) { return g_error.c_str(); }
+
+RT_API int rt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return set_error(RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_context **out) {
+    if (!out) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_context_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_error(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
+    if (device < 0 || device >= n) return set_error(RT_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    DeviceGuard guard(device);
+    if (!guard.ok) return set_error(RT_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    rt_context *c = new (std::nothrow) rt_context();
+    if (!c) return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    c->device = device;
+    c->flags = flags;
+    c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return set_error(RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        c->owns_stream = true;
+    }
+    if (hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
+        delete c;
+        return set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+    }
+    *out = c;
+    return RT_OK;
+}
+
+RT_API int rt_context_destroy(rt_context *c) {
+    if (!c) return RT_OK;
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->ray_o.release();
+    c->ray_d.release();
+    c->hit.release();
+    c->beta.release();
+    c->radiance.release();
+    c->queue[0].release();
+    c->queue[1].release();
+    c->counts.release();
+    c->counters.release();
+    c->accum.release();
+    c->ray_stage.release();
+    c->hit_stage.release();
+    if (c->host_counts) (void)hipHostFree(c->host_counts);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+RT_API int rt_context_synchronize(rt_context *c) {
+    if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+RT_API int rt_context_set_max_paths(rt_context *c, uint64_t max_paths) {
+    if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
+    c->max_paths = max_paths ? max_paths : (1ull << 24);
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **out) {
+    if (!c || !desc || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
+    *out = nullptr;
+    rt::HostScene hs;
+    std::string err;
+    int rc;
+    try {
+        rc = rt::build_host_scene(desc, hs, err);
+    } catch (const std::bad_alloc &) {
+        return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory while building the scene");
+    } catch (const std::exception &e) {
+        return set_error(RT_ERR_INVALID_ARGUMENT, "scene build failed: %s", e.what());
+    }
+    if (rc) return set_error(rc, "%s", err.c_str());
+    if (hs.has_mix) return set_error(RT_ERR_UNSUPPORTED, "Mix materials are not supported by the device path yet");
+
+    DeviceGuard guard(c->device);
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    s->device = c->device;
+    uint64_t bytes = 0;
+    rc = upload(s, hs.nodes, &s->dev.nodes, bytes);
+    if (!rc) rc = upload(s, hs.prims, &s->dev.prims, bytes);
+    if (!rc) rc = upload(s, hs.tri_shade, &s->dev.tri_shade, bytes);
+    if (!rc) rc = upload(s, hs.materials, &s->dev.materials, bytes);
+    if (!rc) rc = upload(s, hs.textures, &s->dev.textures, bytes);
+    if (!rc) rc = upload(s, hs.texels, &s->dev.texels, bytes);
+    if (!rc) rc = upload(s, hs.slot_of_prim, &s->dev.slot_of_prim, bytes);
+    if (rc) {
+        rt_scene_destroy(s);
+        return rc;
+    }
+    s->dev.n_nodes = (uint32_t)hs.nodes.size();
+    s->dev.n_prims = (uint32_t)hs.prims.size();
+    s->dev.n_materials = (uint32_t)hs.materials.size();
+    s->dev.n_textures = (uint32_t)hs.textures.size();
+    s->need_uv = hs.need_uv;
+    s->prim_of_slot.swap(hs.prim_of_slot);
+    s->info.num_triangles = hs.n_triangles;
+    s->info.num_spheres = hs.n_spheres;
+    s->info.num_nodes = s->dev.n_nodes;
+    s->info.depth = hs.depth;
+    std::memcpy(s->info.bounds_min, hs.nodes[0].bmin, 12);
+    std::memcpy(s->info.bounds_max, hs.nodes[0].bmax, 12);
+    s->info.device_bytes = bytes;
+    *out = s;
+    return RT_OK;
+}
+
+RT_API int rt_scene_destroy(rt_scene *s) {
+    if (!s) return RT_OK;
+    DeviceGuard guard(s->device);
+    for (int i = 0; i < s->n_blocks; ++i)
+        if (s->blocks[i]) (void)hipFree(s->blocks[i]);
+    delete s;
+    return RT_OK;
+}
+
+RT_API int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
+    if (!s || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_scene_get_info: null argument");
+    *out = s->info;
+    return RT_OK;
+}
+
+RT_API int rt_scene_export_bvh(const rt_scene *s, float *boxes, int32_t *leaf_prim, uint32_t *skip) {
+    if (!s || !boxes || !leaf_prim || !skip) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_scene_export_bvh: null argument");
+    DeviceGuard guard(s->device);
+    std::vector<rt::Node> nodes(s->dev.n_nodes);
+    HIP_TRY(hipMemcpy(nodes.data(), s->dev.nodes, nodes.size() * sizeof(rt::Node), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        std::memcpy(boxes + 6 * i, nodes[i].bmin, 12);
+        std::memcpy(boxes + 6 * i + 3, nodes[i].bmax, 12);
+        skip[i] = nodes[i].skip;
+        leaf_prim[i] = nodes[i].leaf == rt::kInterior ? -1 : (int32_t)s->prim_of_slot[nodes[i].leaf & ~rt::kSphereBit];
+    }
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Camera (src/camera.rs:20-64), host only
+// ------------------------------------------------------------------------------------------------------
+RT_API int rt_camera_settings_default(rt_camera_settings *s) {
+    if (!s) return set_error(RT_ERR_INVALID_ARGUMENT, "null argument");
+    std::memset(s, 0, sizeof *s);
+    s->y_fov = 80.0f * (3.14159265358979323846f / 180.0f); // 80.0f32.to_radians()
+    s->z_near = 0.0001f;
+    s->z_far = std::numeric_limits<float>::infinity();
+    s->transform[0] = s->transform[4] = s->transform[8] = 1.0f;
+    s->focus_dist = 10.0f;
+    s->defocus_angle = 0.0f;
+    return RT_OK;
+}
+
+RT_API int rt_camera_from_settings(const rt_camera_settings *s, uint32_t width, uint32_t height, rt_camera *out) {
+    using namespace rt;
+    if (!s || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (width == 0 || height == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "image size must be non-zero");
+    auto xform = [&](V3 p) { // glam Affine3A::transform_point3a
+        const float *m = s->transform;
+        V3 r = V3{m[0], m[1], m[2]} * p.x;
+        r = r + V3{m[3], m[4], m[5]} * p.y;
+        r = r + V3{m[6], m[7], m[8]} * p.z;
+        return r + V3{m[9], m[10], m[11]};
+    };
+    const V3 v_up = V3{0.0f, 1.0f, 0.0f};
+    const float theta = s->y_fov;
+    const float h = tanf(theta / 2.0f);
+    const float viewport_height = 2.0f * h * s->focus_dist;
+    const float viewport_width = viewport_height * ((float)width / (float)height);
+    const V3 look_from = xform(V3{0.0f, 0.0f, 0.0f});
+    const V3 look_at = xform(V3{0.0f, 0.0f, -1.0f});
+    const V3 w = normalize(look_from - look_at);
+    const V3 u = normalize(cross(v_up, w));
+    const V3 v = cross(w, u);
+    const V3 viewport_u = u * viewport_width;
+    const V3 viewport_v = (-v) * viewport_height;
+    const V3 pdu = viewport_u / (float)width;
+    const V3 pdv = viewport_v / (float)height;
+    const V3 upper_left = ((look_from - w * s->focus_dist) - viewport_u / 2.0f) - viewport_v / 2.0f;
+    const V3 p00 = upper_left + (pdu + pdv) * 0.5f;
+    const float defocus_radius = s->focus_dist * tanf((s->defocus_angle / 2.0f) * (3.14159265358979323846f / 180.0f));
+    auto put = [](float *d, V3 a) {
+        d[0] = a.x;
+        d[1] = a.y;
+        d[2] = a.z;
+    };
+    put(out->center, look_from);
+    put(out->pixel_00_loc, p00);
+    put(out->pixel_delta_u, pdu);
+    put(out->pixel_delta_v, pdv);
+    put(out->defocus_disk_u, u * defocus_radius);
+    put(out->defocus_disk_v, v * defocus_radius);
+    out->defocus_angle = s->defocus_angle;
+    out->z_near = s->z_near;
+    out->z_far = s->z_far;
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// closest hit
+// ------------------------------------------------------------------------------------------------------
+RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ray *d_rays, size_t n, float t_min,
+                                   float t_max, int use_bvh, rt_hit *d_out, rt_stats *stats) {
+    if (!c || !s) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest: null context or scene");
+    if (s->device != c->device) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and context are on different devices");
+    if (n > 0xFFFFFFFFull / 2) return set_error(RT_ERR_INVALID_ARGUMENT, "too many rays in one call");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    if (!d_rays || !d_out) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest: null ray or hit buffer");
+    DeviceGuard guard(c->device);
+    if (int rc = ensure_paths(c, n)) return rc;
+    const bool count = stats && (c->flags & RT_CTX_COUNTERS) && use_bvh;
+    if (count) {
+        if (int rc = c->counters.ensure(1)) return rc;
+        HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(rt::ExtendCounters), c->stream));
+    }
+    c->spans.clear();
+    c->ev_used = 0;
+    if (stats) HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
+    rt::launch_pack_rays(c->stream, c->max_blocks, reinterpret_cast<const float *>(d_rays), (uint32_t)n, c->ray_o.ptr,
+                         c->ray_d.ptr);
+    if (int rc = timed_begin(c, K_EXTEND)) return rc;
+    rt::launch_extend(c->stream, c->max_blocks, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, nullptr, nullptr,
+                      (uint32_t)n, t_min, t_max, use_bvh != 0, count ? c->counters.ptr : nullptr);
+    if (int rc = timed_end(c)) return rc;
+    rt::launch_finalize_hits(c->stream, c->max_blocks, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, d_out);
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        HIP_TRY(hipEventRecord(c->ev_end, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev_end));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+        stats->total_ms = ms;
+        stats->rays_traced = n;
+        stats->extend_launches = 1;
+        if (count) {
+            rt::ExtendCounters h;
+            HIP_TRY(hipMemcpy(&h, c->counters.ptr, sizeof h, hipMemcpyDeviceToHost));
+            stats->node_visits = h.node_visits;
+            stats->triangle_tests = h.triangle_tests;
+            stats->sphere_tests = h.sphere_tests;
+        }
+        if (int rc = collect_timing(c, stats)) return rc;
+    }
+    return RT_OK;
+}
+
+RT_API int rt_trace_closest(rt_context *c, const rt_scene *s, const rt_ray *rays, size_t n, float t_min, float t_max,
+                            int use_bvh, rt_hit *out, rt_stats *stats) {
+    if (!c || !s) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest: null context or scene");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    if (!rays || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest: null ray or hit buffer");
+    DeviceGuard guard(c->device);
+    if (int rc = c->ray_stage.ensure(n * 6)) return rc;
+    if (int rc = c->hit_stage.ensure(n * 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->ray_stage.ptr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, c->stream));
+    if (int rc = rt_trace_closest_device(c, s, reinterpret_cast<const rt_ray *>(c->ray_stage.ptr), n, t_min, t_max,
+                                         use_bvh, reinterpret_cast<rt_hit *>(c->hit_stage.ptr), stats))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->hit_stage.ptr, n * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// render
+// ------------------------------------------------------------------------------------------------------
+RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *cam, const rt_settings *st,
+                            float *d_accum, rt_stats *stats) {
+    if (!c || !s || !cam || !st || !d_accum) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
+    if (s->device != c->device) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and context are on different devices");
+    if (st->image_width == 0 || st->image_height == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "image size must be non-zero");
+    const uint64_t npix64 = (uint64_t)st->image_width * st->image_height;
+    if (npix64 > (1ull << 26)) return set_error(RT_ERR_INVALID_ARGUMENT, "image larger than 2^26 pixels");
+    if (st->max_depth > 0xFFFFu) return set_error(RT_ERR_INVALID_ARGUMENT, "max_depth larger than 65535");
+    if (st->mode > RT_MODE_GAMMA_PER_SAMPLE) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown accumulation mode");
+    const uint32_t total = st->sample_count ? st->sample_count : st->samples_per_pixel;
+    if ((uint64_t)st->sample_begin + total > (1ull << 22)) return set_error(RT_ERR_INVALID_ARGUMENT, "sample index beyond 2^22");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (total == 0) return RT_OK;
+    const uint32_t npix = (uint32_t)npix64;
+    DeviceGuard guard(c->device);
+
+    // samples per batch: as many whole frames as fit in the path budget
+    uint64_t per_batch = c->max_paths / npix;
+    per_batch = std::max<uint64_t>(1, std::min<uint64_t>(per_batch, std::min<uint32_t>(total, 0xFFFFu)));
+    const uint32_t B = (uint32_t)per_batch;
+    const size_t slots = (size_t)B * npix;
+    if (slots > 0x7FFFFFFFull) return set_error(RT_ERR_INVALID_ARGUMENT, "batch exceeds 2^31 paths");
+    if (int rc = ensure_render(c, slots, st->max_depth)) return rc;
+    const uint32_t n_batches = (total + B - 1) / B;
+    const size_t counts_len = (size_t)st->max_depth + 2;
+    if (stats)
+        if (int rc = ensure_host_counts(c, counts_len * n_batches)) return rc;
+
+    rt::RenderParams P{};
+    std::memcpy(P.center, cam->center, 12);
+    std::memcpy(P.pixel_00_loc, cam->pixel_00_loc, 12);
+    std::memcpy(P.pixel_delta_u, cam->pixel_delta_u, 12);
+    std::memcpy(P.pixel_delta_v, cam->pixel_delta_v, 12);
+    std::memcpy(P.defocus_disk_u, cam->defocus_disk_u, 12);
+    std::memcpy(P.defocus_disk_v, cam->defocus_disk_v, 12);
+    P.defocus_angle = cam->defocus_angle;
+    P.z_near = cam->z_near;
+    P.z_far = cam->z_far;
+    std::memcpy(P.background, st->background_color, 12);
+    P.width = st->image_width;
+    P.height = st->image_height;
+    P.npix = npix;
+    P.max_depth = st->max_depth;
+    P.mode = st->mode;
+    P.seed_mix = rt::mix64(st->seed);
+
+    rt::PathState ps{c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, c->beta.ptr, c->radiance.ptr};
+    const bool count = stats && (c->flags & RT_CTX_COUNTERS);
+    if (count) HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(rt::ExtendCounters), c->stream));
+    c->spans.clear();
+    c->ev_used = 0;
+    if (stats) HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
+    uint32_t extend_launches = 0, shade_launches = 0;
+
+    for (uint32_t bi = 0; bi < n_batches; ++bi) {
+        const uint32_t s0 = bi * B;
+        const uint32_t b = std::min(B, total - s0);
+        const uint32_t n = b * npix;
+        P.sample_base = st->sample_begin + s0;
+        P.batch_samples = b;
+        HIP_TRY(hipMemsetAsync(c->counts.ptr, 0, counts_len * sizeof(uint32_t), c->stream));
+        if (int rc = timed_begin(c, K_GENERATE)) return rc;
+        rt::launch_generate(c->stream, c->max_blocks, P, ps, n);
+        if (int rc = timed_end(c)) return rc;
+        for (uint32_t it = 0; it < st->max_depth; ++it) {
+            const uint32_t *q_in = it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr;
+            const uint32_t *cnt_in = it == 0 ? nullptr : c->counts.ptr + it;
+            if (int rc = timed_begin(c, K_EXTEND)) return rc;
+            rt::launch_extend(c->stream, c->max_blocks, s->dev, ps.ray_o, ps.ray_d, ps.hit, q_in, cnt_in, n, cam->z_near,
+                              cam->z_far, true, count ? c->counters.ptr : nullptr);
+            if (int rc = timed_end(c)) return rc;
+            if (int rc = timed_begin(c, K_SHADE)) return rc;
+            rt::launch_shade(c->stream, c->max_blocks, s->dev, P, ps, q_in, cnt_in, n, c->queue[it & 1].ptr,
+                             c->counts.ptr + it + 1, s->need_uv);
+            if (int rc = timed_end(c)) return rc;
+            ++extend_launches;
+            ++shade_launches;
+        }
+        if (int rc = timed_begin(c, K_ACCUMULATE)) return rc;
+        rt::launch_accumulate(c->stream, c->max_blocks, P, ps.radiance, d_accum);
+        if (int rc = timed_end(c)) return rc;
+        if (stats)
+            HIP_TRY(hipMemcpyAsync(c->host_counts + counts_len * bi, c->counts.ptr, counts_len * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        HIP_TRY(hipEventRecord(c->ev_end, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev_end));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+        stats->total_ms = ms;
+        uint64_t rays = 0;
+        for (uint32_t bi = 0; bi < n_batches; ++bi) {
+            const uint32_t b = std::min(B, total - bi * B);
+            if (st->max_depth > 0) rays += (uint64_t)b * npix; // iteration 0 traces every path
+            for (uint32_t it = 1; it < st->max_depth; ++it) rays += c->host_counts[counts_len * bi + it];
+        }
+        stats->rays_traced = rays;
+        stats->paths = (uint64_t)total * npix;
+        stats->extend_launches = extend_launches;
+        stats->shade_launches = shade_launches;
+        if (count) {
+            rt::ExtendCounters h;
+            HIP_TRY(hipMemcpy(&h, c->counters.ptr, sizeof h, hipMemcpyDeviceToHost));
+            stats->node_visits = h.node_visits;
+            stats->triangle_tests = h.triangle_tests;
+            stats->sphere_tests = h.sphere_tests;
+        }
+        if (int rc = collect_timing(c, stats)) return rc;
+    }
+    return RT_OK;
+}
+
+RT_API int rt_render(rt_context *c, const rt_scene *s, const rt_camera *cam, const rt_settings *st, float *accum,
+                     rt_stats *stats) {
+    if (!c || !s || !cam || !st || !accum) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
+    if (st->image_width == 0 || st->image_height == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "image size must be non-zero");
+    const size_t n = (size_t)st->image_width * st->image_height * 3;
+    DeviceGuard guard(c->device);
+    if (int rc = c->accum.ensure(n)) return rc;
+    HIP_TRY(hipMemsetAsync(c->accum.ptr, 0, n * sizeof(float), c->stream));
+    if (int rc = rt_render_device(c, s, cam, st, c->accum.ptr, stats)) return rc;
+    HIP_TRY(hipMemcpyAsync(accum, c->accum.ptr, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}

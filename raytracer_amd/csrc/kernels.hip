@@ -1,0 +1,617 @@
+// kernels.hip — the wavefront path tracer for gfx950: generate / extend / shade / accumulate.
+//
+// Every kernel is a grid-stride loop over a queue of path slots whose length lives in device memory, so the
+// host never has to read a count back between bounces.  One lane owns one path.  All arithmetic is binary32
+// in the reference's operation order (built with -ffp-contract=off), including its inf/NaN behaviour.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "rt_math.h"
+
+namespace rt {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
+__device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+// ------------------------------------------------------------------------------------------------------
+// intersection
+// ------------------------------------------------------------------------------------------------------
+
+// Aabb::hit (src/aabb.rs:95-127).  The reference recomputes 1/d per node; the value is the same every time,
+// so it is computed once per ray.  Per axis it orders (t0, t1) with `t0 < t1` and then narrows [lo, hi] by
+// compare-and-assign, which leaves the interval untouched by a NaN; fmaxf/fminf have exactly that
+// behaviour because lo and hi themselves are never NaN.  The per-axis early `max <= min` exits are
+// equivalent to one test at the end because the interval only ever shrinks.
+__device__ __forceinline__ bool box_hit(float4 nlo, float4 nhi, V3 o, V3 inv, float lo, float hi) {
+    float t0 = (nlo.x - o.x) * inv.x;
+    float t1 = (nhi.x - o.x) * inv.x;
+    bool s = t0 < t1;
+    lo = fmaxf(lo, s ? t0 : t1);
+    hi = fminf(hi, s ? t1 : t0);
+    t0 = (nlo.y - o.y) * inv.y;
+    t1 = (nhi.y - o.y) * inv.y;
+    s = t0 < t1;
+    lo = fmaxf(lo, s ? t0 : t1);
+    hi = fminf(hi, s ? t1 : t0);
+    t0 = (nlo.z - o.z) * inv.z;
+    t1 = (nhi.z - o.z) * inv.z;
+    s = t0 < t1;
+    lo = fmaxf(lo, s ? t0 : t1);
+    hi = fminf(hi, s ? t1 : t0);
+    return !(hi <= lo);
+}
+
+struct Closest {
+    float t;
+    uint32_t slot;
+    float u, v;
+};
+
+// TriangleRef::hit up to the range test (src/object/triangle_mesh.rs:140-170): Möller–Trumbore without
+// culling, `contains` is inclusive at both ends.
+__device__ __forceinline__ void tri_test(const float4 *__restrict__ prim, uint32_t slot, V3 o, V3 d, float tmin,
+                                         Closest &best) {
+    float4 a = prim[0], b = prim[1], c = prim[2];
+    V3 v0 = xyz(a), e1 = xyz(b), e2 = xyz(c);
+    V3 p = cross(d, e2);
+    float det = dot(e1, p);
+    if (fabsf(det) < 1.1920929e-07f) return;
+    float inv_det = 1.0f / det;
+    V3 tv = o - v0;
+    float u = dot(tv, p) * inv_det;
+    if (u < 0.0f || u > 1.0f) return;
+    V3 q = cross(tv, e1);
+    float v = dot(d, q) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return;
+    float t = dot(e2, q) * inv_det;
+    if (!(tmin <= t && t <= best.t)) return;
+    best.t = t;
+    best.slot = slot;
+    best.u = u;
+    best.v = v;
+}
+
+// Sphere::hit up to the range test (src/object/sphere.rs:55-72): `surrounds` is exclusive.
+__device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uint32_t slot, V3 o, V3 d, float tmin,
+                                            Closest &best) {
+    float4 a = prim[0];
+    V3 oc = xyz(a) - o;
+    float aa = length_squared(d);
+    float h = dot(d, oc);
+    float c = length_squared(oc) - a.w * a.w;
+    float discriminant = h * h - aa * c;
+    if (discriminant < 0.0f) return;
+    float sqrtd = sqrtf(discriminant);
+    float root = (h - sqrtd) / aa;
+    if (!(tmin < root && root < best.t)) {
+        root = (h + sqrtd) / aa;
+        if (!(tmin < root && root < best.t)) return;
+    }
+    best.t = root;
+    best.slot = slot | kSphereBit;
+    best.u = 0.0f;
+    best.v = 0.0f;
+}
+
+// BvhNode::hit (src/bvh.rs:295-317) as a stackless pre-order walk.  `best.t` plays the role of the
+// shrinking `hit_range.max`: the reference hands the right sibling max = the left hit's distance, and every
+// later node therefore sees the closest distance found so far in visiting order.
+template <bool COUNT>
+__device__ __forceinline__ Closest traverse(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax,
+                                            uint32_t &n_nodes_visited, uint32_t &n_tri, uint32_t &n_sph) {
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
+    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    uint32_t idx = 0;
+    const uint32_t end = sc.n_nodes;
+    while (idx < end) {
+        float4 nlo = nodes[2 * idx];
+        float4 nhi = nodes[2 * idx + 1];
+        if (COUNT) ++n_nodes_visited;
+        bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+        uint32_t leaf = f2u(nhi.w);
+        if (hit && leaf != kInterior) {
+            uint32_t slot = leaf & ~kSphereBit;
+            if (leaf & kSphereBit) {
+                if (COUNT) ++n_sph;
+                sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+            } else {
+                if (COUNT) ++n_tri;
+                tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+            }
+        }
+        idx = hit ? idx + 1 : f2u(nlo.w);
+    }
+    return best;
+}
+
+// World::hit (src/object/world.rs:21-39): every object in list order with a shrinking max.
+__device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax) {
+    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
+    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    for (uint32_t id = 0; id < sc.n_prims; ++id) {
+        uint32_t leaf = sc.slot_of_prim[id];
+        uint32_t slot = leaf & ~kSphereBit;
+        if (leaf & kSphereBit)
+            sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+        else
+            tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+    }
+    return best;
+}
+
+__device__ __forceinline__ uint32_t queue_count(const uint32_t *count_ptr, uint32_t count_imm) {
+    return count_ptr ? *count_ptr : count_imm;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// surface reconstruction and materials
+// ------------------------------------------------------------------------------------------------------
+struct Surface {
+    V3 point;
+    V3 normal; // face-forwarded
+    bool front_facing;
+    float tu, tv; // texture coordinates
+    uint32_t material;
+    uint32_t prim_id;
+};
+
+// src/object/sphere.rs:42-52.  Only evaluated for image-textured spheres; acosf/atan2f are the device
+// library's and may differ from the host libm by a few ULP.
+__device__ __forceinline__ void sphere_uv(V3 p, float &u, float &v) {
+    const float PI = 3.14159265358979323846f;
+    float theta = acosf(-p.y);
+    float phi = atan2f(-p.z, p.x) + PI;
+    u = phi / (2.0f * PI);
+    v = theta / PI;
+}
+
+// What TriangleRef::hit / Sphere::hit compute after the range test plus HitRecord::new
+// (src/object/triangle_mesh.rs:172-187, src/object/sphere.rs:73-82, src/object/mod.rs:39-62).
+template <bool NEED_UV>
+__device__ __forceinline__ Surface make_surface(const SceneDev &sc, V3 o, V3 d, float t, uint32_t leaf, float u,
+                                                float v) {
+    Surface s;
+    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
+    uint32_t slot = leaf & ~kSphereBit;
+    s.point = o + d * t;
+    V3 outward;
+    s.tu = 0.0f;
+    s.tv = 0.0f;
+    if (leaf & kSphereBit) {
+        float4 a = prims[3 * (size_t)slot];
+        float4 b = prims[3 * (size_t)slot + 1];
+        outward = (s.point - xyz(a)) / a.w;
+        s.prim_id = f2u(b.x);
+        s.material = f2u(b.y);
+        if (NEED_UV) sphere_uv(s.point, s.tu, s.tv);
+    } else {
+        float4 a = prims[3 * (size_t)slot];
+        float4 b = prims[3 * (size_t)slot + 1];
+        s.prim_id = f2u(a.w);
+        s.material = f2u(b.w);
+        const float4 *__restrict__ sh = reinterpret_cast<const float4 *>(sc.tri_shade + slot);
+        float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+        uint32_t flags = f2u(s3.w);
+        V3 n0 = V3{s0.x, s0.y, s0.z};
+        if (flags & kTriHasNormals) {
+            V3 n1 = V3{s0.w, s1.x, s1.y};
+            V3 n2 = V3{s1.z, s1.w, s2.x};
+            outward = (n0 * (1.0f - u - v) + n1 * u) + n2 * v;
+        } else {
+            outward = n0;
+        }
+        if (NEED_UV && (flags & kTriHasUvs)) {
+            float w = 1.0f - u - v;
+            s.tu = s2.y * w + s2.w * u + s3.y * v;
+            s.tv = s2.z * w + s3.x * u + s3.z * v;
+        }
+    }
+    s.front_facing = dot(d, outward) < 0.0f;
+    s.normal = s.front_facing ? outward : -outward;
+    return s;
+}
+
+__device__ __forceinline__ long long f32_to_i64_sat(float f) { // Rust `as i64`
+    if (f != f) return 0;
+    if (f >= 9223372036854775808.0f) return 0x7FFFFFFFFFFFFFFFll;
+    if (f <= -9223372036854775808.0f) return (long long)0x8000000000000000ull;
+    return (long long)f;
+}
+__device__ __forceinline__ uint32_t f32_to_u32_sat(float f) { // Rust `as u32`
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+__device__ __forceinline__ float clamp01(float x) { // Range::UNIT.clamp (src/range.rs:44-52)
+    if (x < 0.0f) return 0.0f;
+    if (x > 1.0f) return 1.0f;
+    return x;
+}
+
+// Texture::value_at (src/texture.rs:47-51,70-83,115-136).
+__device__ V3 texture_value(const SceneDev &sc, int32_t ti, float tu, float tv, V3 p) {
+    for (uint32_t guard = 0; guard <= sc.n_textures; ++guard) {
+        const TextureRec &t = sc.textures[ti];
+        if (t.kind == 0u) return ld3(t.rgb);
+        if (t.kind == 1u) {
+            long long x = f32_to_i64_sat(floorf(t.inv_scale * p.x));
+            long long y = f32_to_i64_sat(floorf(t.inv_scale * p.y));
+            long long z = f32_to_i64_sat(floorf(t.inv_scale * p.z));
+            long long sum = (long long)((unsigned long long)x + (unsigned long long)y + (unsigned long long)z);
+            ti = (sum % 2 == 0) ? t.even : t.odd;
+            continue;
+        }
+        if (t.height == 0u || t.width == 0u) return V3{0.0f, 1.0f, 1.0f};
+        float cu = clamp01(tu);
+        float cv = 1.0f - clamp01(tv);
+        uint32_t i = f32_to_u32_sat(cu * (float)t.width);
+        i = min(i, t.height - 1u); // the reference clamps the column with the HEIGHT (src/texture.rs:125)
+        i = min(i, t.width - 1u);  // where it would index past the row (a panic there) stay inside it
+        uint32_t j = min(f32_to_u32_sat(cv * (float)t.height), t.height - 1u);
+        const uint8_t *px = sc.texels + t.pixel_offset + 3ull * ((unsigned long long)j * t.width + i);
+        const float color_scale = 1.0f / 255.0f;
+        return V3{(float)px[0] * color_scale, (float)px[1] * color_scale, (float)px[2] * color_scale};
+    }
+    return V3{0.0f, 0.0f, 0.0f};
+}
+
+__device__ __forceinline__ V3 material_color(const SceneDev &sc, const MaterialRec &m, const Surface &s) {
+    if (m.solid) return ld3(m.rgb);
+    return texture_value(sc, m.texture, s.tu, s.tv, s.point);
+}
+
+// src/sample.rs:7-30 with src/math.rs:3-5: the concentric-disk sampler binds (radius, angle) to
+// (theta, r); kept as written, so the returned vector can be longer than 1 and z collapses to 0.
+__device__ __forceinline__ V3 cosine_hemisphere(float ux, float uy) {
+    const float FRAC_PI_4 = 0.785398163397448309615660845819875721f;
+    const float FRAC_PI_2 = 1.57079632679489661923132169163975144f;
+    float ox = 2.0f * ux - 1.0f;
+    float oy = 2.0f * uy - 1.0f;
+    float dx, dy;
+    if (ox == 0.0f && oy == 0.0f) {
+        dx = 1.0f;
+        dy = 1.0f;
+    } else {
+        float theta, r;
+        if (fabsf(ox) > fabsf(oy)) {
+            theta = ox;
+            r = FRAC_PI_4 * (oy / ox);
+        } else {
+            theta = oy;
+            r = FRAC_PI_2 - FRAC_PI_4 * (ox / oy);
+        }
+        dx = r * cos_unit(theta);
+        dy = r * sin_unit(theta);
+    }
+    float z = sqrtf(fmaxf(1.0f - (dx * dx) - (dy * dy), 0.0f));
+    return V3{dx, dy, z};
+}
+
+// src/vec3.rs:65-72,83-85
+__device__ __forceinline__ V3 gen_unit_vector(Rng &rng) {
+    for (;;) {
+        float x = rng_random_range(rng, -1.0f, 1.0f);
+        float y = rng_random_range(rng, -1.0f, 1.0f);
+        float z = rng_random_range(rng, -1.0f, 1.0f);
+        V3 p = V3{x, y, z};
+        if (length_squared(p) < 1.0f) return normalize(p);
+    }
+}
+
+// src/material.rs:116-121; powi(5) is x * ((x*x) * (x*x)).
+__device__ __forceinline__ float reflectance(float cosine, float refraction_index) {
+    float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
+    r0 *= r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    float x5 = x * (x2 * x2);
+    return r0 + (1.0f - r0) * x5;
+}
+
+struct Scatter {
+    V3 attenuation;
+    V3 direction;
+    float pdf; // 1 when the reference's pdf is None (src/renderer.rs:53)
+};
+
+// Scatterable::scatter for the four leaf materials (src/material.rs:47-64,72-82,89-114,129-132).
+__device__ __forceinline__ bool scatter_leaf(const SceneDev &sc, const MaterialRec &m, V3 d, const Surface &s, Rng &rng,
+                                             Scatter &out) {
+    const float FRAC_1_PI = 0.318309886183790671537767526745028724f;
+    switch (m.kind) {
+    case 0u: { // Lambertian: world-space sample, no shading frame
+        uint32_t a, b;
+        rng_next_2u32(rng, a, b);
+        V3 w_i = cosine_hemisphere(u32_to_unit(a), u32_to_unit(b));
+        if (-d.z < 0.0f) w_i.z *= -1.0f;
+        out.direction = w_i;
+        out.attenuation = material_color(sc, m, s) * FRAC_1_PI;
+        out.pdf = fabsf(w_i.z) * FRAC_1_PI;
+        return true;
+    }
+    case 1u: { // Metal
+        V3 reflected = reflect(d, s.normal);
+        V3 fuzz = gen_unit_vector(rng) * m.param;
+        out.direction = normalize(reflected) + fuzz;
+        out.attenuation = material_color(sc, m, s);
+        out.pdf = 1.0f;
+        return true;
+    }
+    case 2u: { // Dielectric
+        float ri = s.front_facing ? 1.0f / m.param : m.param;
+        V3 unit_direction = normalize(d);
+        float cos_theta = fminf(dot(-unit_direction, s.normal), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = ri * sin_theta > 1.0f;
+        if (cannot_refract || reflectance(cos_theta, ri) > rng_random(rng))
+            out.direction = reflect(unit_direction, s.normal);
+        else
+            out.direction = refract(unit_direction, s.normal, ri);
+        out.attenuation = V3{1.0f, 1.0f, 1.0f};
+        out.pdf = 1.0f;
+        return true;
+    }
+    default: // DiffuseLight
+        return false;
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// generate: Camera::get_ray (src/camera.rs:68-93) for every (sample, pixel) of the batch
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(RenderParams P, PathState st, uint32_t n_slots) {
+    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n_slots; slot += gridDim.x * kBlock) {
+        uint32_t s_local = slot / P.npix;
+        uint32_t pixel = slot - s_local * P.npix;
+        uint32_t j = pixel / P.width;
+        uint32_t i = pixel - j * P.width;
+        Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, 0u);
+        uint32_t a, b;
+        rng_next_2u32(rng, a, b);
+        float ox = u32_to_unit(a) - 0.5f;
+        float oy = u32_to_unit(b) - 0.5f;
+        V3 pixel_sample = (ld3(P.pixel_00_loc) + ld3(P.pixel_delta_u) * ((float)i + ox)) +
+                          ld3(P.pixel_delta_v) * ((float)j + oy);
+        V3 origin;
+        if (P.defocus_angle <= 0.0f) {
+            origin = ld3(P.center);
+        } else {
+            float px, py; // gen_unit_disk (src/vec3.rs:74-81)
+            for (;;) {
+                px = rng_random_range(rng, -1.0f, 1.0f);
+                py = rng_random_range(rng, -1.0f, 1.0f);
+                V3 p = V3{px, py, 0.0f};
+                if (length_squared(p) < 1.0f) break;
+            }
+            origin = (ld3(P.center) + ld3(P.defocus_disk_u) * px) + ld3(P.defocus_disk_v) * py;
+        }
+        V3 dir = pixel_sample - origin;
+        st.ray_o[slot] = mk4(origin, u2f(rng.k));
+        st.ray_d[slot] = mk4(dir, u2f(s_local << 16));
+        st.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        st.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// extend: closest hit of every queued ray
+// ------------------------------------------------------------------------------------------------------
+template <bool COUNT, bool USE_BVH>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__restrict__ ray_o,
+                                                   const float4 *__restrict__ ray_d, float4 *__restrict__ hits,
+                                                   const uint32_t *__restrict__ queue, const uint32_t *count_ptr,
+                                                   uint32_t count_imm, float tmin, float tmax,
+                                                   ExtendCounters *counters) {
+    const uint32_t count = queue_count(count_ptr, count_imm);
+    uint32_t c_nodes = 0, c_tri = 0, c_sph = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+        uint32_t slot = queue ? queue[i] : i;
+        V3 o = xyz(ray_o[slot]);
+        V3 d = xyz(ray_d[slot]);
+        Closest best = USE_BVH ? traverse<COUNT>(sc, o, d, tmin, tmax, c_nodes, c_tri, c_sph)
+                               : scan_world(sc, o, d, tmin, tmax);
+        hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
+    }
+    if (COUNT) {
+        atomicAdd(&counters->node_visits, (unsigned long long)c_nodes);
+        atomicAdd(&counters->triangle_tests, (unsigned long long)c_tri);
+        atomicAdd(&counters->sphere_tests, (unsigned long long)c_sph);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// shade: the body of Renderer::ray_color's loop after `world.hit` (src/renderer.rs:46-66)
+// ------------------------------------------------------------------------------------------------------
+template <bool NEED_UV>
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, PathState st,
+                                                  const uint32_t *__restrict__ queue_in, const uint32_t *count_ptr,
+                                                  uint32_t count_imm, uint32_t *__restrict__ queue_out,
+                                                  uint32_t *count_out) {
+    const uint32_t count = queue_count(count_ptr, count_imm);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = gridDim.x * kBlock;
+    // Whole waves iterate together so that the ballot below always sees all 64 lanes.
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < count; base += stride) {
+        const uint32_t i = base + lane;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < count) {
+            slot = queue_in ? queue_in[i] : i;
+            float4 h = st.hit[slot];
+            float4 o4 = st.ray_o[slot];
+            float4 d4 = st.ray_d[slot];
+            uint32_t leaf = f2u(h.y);
+            V3 l = xyz(st.radiance[slot]);
+            if (leaf == kMissSlot) {
+                // src/renderer.rs:59-63: the background REPLACES the radiance gathered so far.
+                l = ld3(P.background);
+            } else {
+                V3 o = xyz(o4), d = xyz(d4);
+                V3 beta = xyz(st.beta[slot]);
+                uint32_t meta = f2u(d4.w);
+                uint32_t depth = meta & 0xFFFFu;
+                uint32_t s_local = meta >> 16;
+                Surface s = make_surface<NEED_UV>(sc, o, d, h.x, leaf, h.z, h.w);
+                const MaterialRec m = sc.materials[s.material];
+                // src/renderer.rs:48: l += beta * emit.  Non-emitters contribute beta * 0, which is NaN once
+                // beta holds an infinity, exactly as in the reference.
+                V3 emit = V3{0.0f, 0.0f, 0.0f};
+                if (m.kind == 3u) emit = material_color(sc, m, s) * m.param;
+                l = l + beta * emit;
+                uint32_t pixel = slot - s_local * P.npix;
+                Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, f2u(o4.w));
+                Scatter sr;
+                if (scatter_leaf(sc, m, d, s, rng, sr)) {
+                    // src/renderer.rs:51-54
+                    V3 f = (sr.attenuation * fabsf(dot(sr.direction, s.normal))) / sr.pdf;
+                    beta = beta * f;
+                    depth += 1u;
+                    // src/renderer.rs:39-41: `while beta != 0` then `depth >= max_depth`
+                    alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
+                    if (alive) {
+                        st.ray_o[slot] = mk4(s.point, u2f(rng.k));
+                        st.ray_d[slot] = mk4(sr.direction, u2f((s_local << 16) | depth));
+                        st.beta[slot] = mk4(beta, 0.0f);
+                    }
+                }
+            }
+            st.radiance[slot] = mk4(l, 0.0f);
+        }
+        // Queue compaction: one atomic per wave, lanes ranked by ballot + popcount.
+        unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t total = __popcll(mask);
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(count_out, total);
+            start = __shfl(start, 0);
+            if (alive) queue_out[start + rank] = slot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// accumulate: fold the batch's per-path radiance into the image, samples in ascending order
+// (src/renderer.rs:87-93 for LINEAR_MEAN; :132-137 with linear_to_gamma :159-165 for GAMMA_PER_SAMPLE)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_accumulate(RenderParams P, const float4 *__restrict__ radiance,
+                                                       float *__restrict__ accum) {
+    for (uint32_t pixel = blockIdx.x * kBlock + threadIdx.x; pixel < P.npix; pixel += gridDim.x * kBlock) {
+        float r = accum[3 * (size_t)pixel], g = accum[3 * (size_t)pixel + 1], b = accum[3 * (size_t)pixel + 2];
+        for (uint32_t s = 0; s < P.batch_samples; ++s) {
+            float4 l = radiance[(size_t)s * P.npix + pixel];
+            if (P.mode == 1u) {
+                l.x = l.x > 0.0f ? sqrtf(l.x) : 0.0f;
+                l.y = l.y > 0.0f ? sqrtf(l.y) : 0.0f;
+                l.z = l.z > 0.0f ? sqrtf(l.z) : 0.0f;
+            }
+            r += l.x;
+            g += l.y;
+            b += l.z;
+        }
+        accum[3 * (size_t)pixel] = r;
+        accum[3 * (size_t)pixel + 1] = g;
+        accum[3 * (size_t)pixel + 2] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// helpers of rt_trace_closest: AoS rays -> wavefront layout, wavefront hits -> rt_hit records
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack_rays(const float *__restrict__ rays, uint32_t n, float4 *ray_o,
+                                                      float4 *ray_d) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float *r = rays + 6 * (size_t)i;
+        ray_o[i] = make_float4(r[0], r[1], r[2], 0.0f);
+        ray_d[i] = make_float4(r[3], r[4], r[5], 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_finalize_hits(SceneDev sc, const float4 *__restrict__ ray_o,
+                                                          const float4 *__restrict__ ray_d,
+                                                          const float4 *__restrict__ hits, uint32_t n,
+                                                          uint32_t *__restrict__ out) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        float4 h = hits[i];
+        uint32_t leaf = f2u(h.y);
+        uint32_t *o = out + 8 * (size_t)i;
+        if (leaf == kMissSlot) {
+            o[0] = 0u; o[1] = 0xFFFFFFFFu; o[2] = 0u; o[3] = 0u; o[4] = 0u; o[5] = 0u; o[6] = 0u; o[7] = 0u;
+            continue;
+        }
+        Surface s = make_surface<false>(sc, xyz(ray_o[i]), xyz(ray_d[i]), h.x, leaf, h.z, h.w);
+        o[0] = f2u(h.x);
+        o[1] = s.prim_id;
+        o[2] = f2u(h.z);
+        o[3] = f2u(h.w);
+        o[4] = f2u(s.normal.x);
+        o[5] = f2u(s.normal.y);
+        o[6] = f2u(s.normal.z);
+        o[7] = s.front_facing ? 1u : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+static inline uint32_t grid_for(uint64_t items, uint32_t max_blocks) {
+    uint64_t need = (items + kBlock - 1) / kBlock;
+    if (need < 1) need = 1;
+    return (uint32_t)(need < max_blocks ? need : max_blocks);
+}
+
+void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const PathState &st, uint32_t n_slots) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(n_slots, max_blocks)), dim3(kBlock), 0, s, P, st, n_slots);
+}
+
+void launch_extend(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
+                   float4 *hits, const uint32_t *queue, const uint32_t *count_ptr, uint32_t count_bound, float tmin,
+                   float tmax, bool use_bvh, ExtendCounters *counters) {
+    dim3 g(grid_for(count_bound, max_blocks)), b(kBlock);
+    uint32_t imm = count_ptr ? 0u : count_bound;
+    if (!use_bvh)
+        hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, sc, ray_o, ray_d, hits, queue, count_ptr, imm, tmin, tmax,
+                           counters);
+    else if (counters)
+        hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, sc, ray_o, ray_d, hits, queue, count_ptr, imm, tmin, tmax,
+                           counters);
+    else
+        hipLaunchKernelGGL((k_extend<false, true>), g, b, 0, s, sc, ray_o, ray_d, hits, queue, count_ptr, imm, tmin, tmax,
+                           counters);
+}
+
+void launch_shade(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const RenderParams &P, const PathState &st,
+                  const uint32_t *queue_in, const uint32_t *count_ptr, uint32_t count_bound, uint32_t *queue_out,
+                  uint32_t *count_out, bool need_uv) {
+    dim3 g(grid_for(count_bound, max_blocks)), b(kBlock);
+    uint32_t imm = count_ptr ? 0u : count_bound;
+    if (need_uv)
+        hipLaunchKernelGGL((k_shade<true>), g, b, 0, s, sc, P, st, queue_in, count_ptr, imm, queue_out, count_out);
+    else
+        hipLaunchKernelGGL((k_shade<false>), g, b, 0, s, sc, P, st, queue_in, count_ptr, imm, queue_out, count_out);
+}
+
+void launch_accumulate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const float4 *radiance, float *accum) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(P.npix, max_blocks)), dim3(kBlock), 0, s, P, radiance, accum);
+}
+
+void launch_pack_rays(hipStream_t s, uint32_t max_blocks, const float *rays, uint32_t n, float4 *ray_o, float4 *ray_d) {
+    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n, max_blocks)), dim3(kBlock), 0, s, rays, n, ray_o, ray_d);
+}
+
+void launch_finalize_hits(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const float4 *ray_o,
+                          const float4 *ray_d, const float4 *hits, uint32_t n, void *out) {
+    hipLaunchKernelGGL(k_finalize_hits, dim3(grid_for(n, max_blocks)), dim3(kBlock), 0, s, sc, ray_o, ray_d, hits, n,
+                       reinterpret_cast<uint32_t *>(out));
+}
+
+} // namespace rt

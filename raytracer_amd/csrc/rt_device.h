@@ -1,0 +1,136 @@
+// rt_device.h — layout of the scene tables and wavefront state in HBM.  Shared by host and device code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+constexpr uint32_t kInterior = 0xFFFFFFFFu; // Node::leaf of an interior node
+constexpr uint32_t kSphereBit = 0x80000000u; // set in Node::leaf / hit slot for a sphere leaf
+constexpr uint32_t kMissSlot = 0xFFFFFFFFu;
+
+// One BVH node, 32 bytes = two 16-byte loads.  Nodes are stored in pre-order (the order
+// BvhNode::hit visits them, src/bvh.rs:295-317): the left child of node i is node i + 1 and `skip` is the
+// node that follows i's whole subtree, so "box hit -> i + 1, box miss -> skip" walks the tree in exactly the
+// reference's always-left-first order without a stack.  A leaf's `skip` is i + 1.
+struct alignas(16) Node {
+    float bmin[3];
+    uint32_t skip;
+    float bmax[3];
+    uint32_t leaf; // kInterior, or index into the leaf-ordered primitive table (| kSphereBit)
+};
+static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
+
+// One primitive of the intersection table, 48 bytes, stored in leaf (pre-order) order.
+//   triangle: a = v0.xyz | prim_id, b = e1.xyz | material, c = e2.xyz | flags    (e1 = v1 - v0, e2 = v2 - v0,
+//             the same subtractions TriangleRef::hit performs per call, src/object/triangle_mesh.rs:144-145)
+//   sphere:   a = center.xyz | radius, b = prim_id, material, 0, 0
+struct alignas(16) Prim {
+    float a[4];
+    float b[4];
+    float c[4];
+};
+static_assert(sizeof(Prim) == 48, "Prim must be 48 bytes");
+
+constexpr uint32_t kTriHasNormals = 1u; // all three vertex normals exist (else n0 = geometric normal)
+constexpr uint32_t kTriHasUvs = 2u;
+
+// Shading attributes of a triangle, 64 bytes, same order as the Prim table.
+struct alignas(16) TriShade {
+    float n0[3];
+    float n1[3];
+    float n2[3];
+    float uv0[2];
+    float uv1[2];
+    float uv2[2];
+    uint32_t flags;
+};
+static_assert(sizeof(TriShade) == 64, "TriShade must be 64 bytes");
+
+// `enum Material` (src/material.rs:141-148) as a tagged record.  When the material's texture is a
+// SolidColor its colour is copied into `rgb` and `solid` is 1, so the common case needs no texture fetch.
+struct alignas(16) MaterialRec {
+    uint32_t kind;
+    int32_t texture;
+    float param;
+    uint32_t solid;
+    float rgb[3];
+    int32_t left;
+    int32_t right;
+    uint32_t pad[3];
+};
+static_assert(sizeof(MaterialRec) == 48, "MaterialRec must be 48 bytes");
+
+// `enum Texture` (src/texture.rs:140-144).  Image texels live in one RGB8 blob at `pixel_offset`.
+struct alignas(16) TextureRec {
+    uint32_t kind;
+    float rgb[3];
+    float inv_scale;
+    int32_t even;
+    int32_t odd;
+    uint32_t width;
+    uint32_t height;
+    uint32_t pad;
+    uint64_t pixel_offset;
+};
+static_assert(sizeof(TextureRec) == 48, "TextureRec must be 48 bytes");
+
+// Device pointers of one uploaded scene.
+struct SceneDev {
+    const Node *nodes;
+    const Prim *prims;
+    const TriShade *tri_shade;
+    const MaterialRec *materials;
+    const TextureRec *textures;
+    const uint8_t *texels;
+    const uint32_t *slot_of_prim; // primitive ID -> slot in `prims` (object-list order for World::hit)
+    uint32_t n_nodes;
+    uint32_t n_prims;
+    uint32_t n_materials;
+    uint32_t n_textures;
+};
+
+// `Camera` (src/camera.rs:6-17) + the per-call constants of the integrator, passed by value to kernels.
+struct RenderParams {
+    float center[3];
+    float pixel_00_loc[3];
+    float pixel_delta_u[3];
+    float pixel_delta_v[3];
+    float defocus_disk_u[3];
+    float defocus_disk_v[3];
+    float defocus_angle;
+    float z_near;
+    float z_far;
+    float background[3];
+    uint32_t width;
+    uint32_t height;
+    uint32_t npix;
+    uint32_t max_depth;
+    uint32_t mode;
+    uint32_t sample_base; // global index of the batch's first sample
+    uint32_t batch_samples;
+    uint64_t seed_mix;
+};
+
+// Wavefront state, one entry per path slot (slot = sample_in_batch * npix + pixel).
+//   ray_o  = origin.xyz    | k     (index of the path's next random draw)
+//   ray_d  = direction.xyz | meta  (depth in bits 0..15, sample_in_batch in bits 16..31)
+//   hit    = t, slot (| kSphereBit, kMissSlot on a miss), u, v
+//   beta   = throughput.xyz | unused
+//   radiance = l.xyz | unused
+struct PathState {
+    float4 *ray_o;
+    float4 *ray_d;
+    float4 *hit;
+    float4 *beta;
+    float4 *radiance;
+};
+
+struct ExtendCounters {
+    unsigned long long node_visits;
+    unsigned long long triangle_tests;
+    unsigned long long sphere_tests;
+};
+
+} // namespace rt

@@ -1,0 +1,198 @@
+// rt_math.h — binary32 vector arithmetic, sin/cos and the per-path random stream, shared by the HIP kernels
+// and the host-side scene preparation.
+//
+// Everything here must round exactly like the reference's glam::Vec3A code on baseline x86-64
+// (src/vec3.rs:1-3): one IEEE operation per source operation, no FMA contraction (the build passes
+// -ffp-contract=off), correctly rounded division and square root.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+struct V3 {
+    float x, y, z;
+};
+
+RT_HD V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RT_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_HD V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_HD V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RT_HD V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+RT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+// glam 0.28 dot: (x*x' + y*y') + z*z'
+RT_HD float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// glam 0.28 cross: each lane is one product minus another
+RT_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT_HD float length_squared(V3 a) { return dot(a, a); }
+// glam 0.28 normalize: v * (1 / sqrt(v.v))
+RT_HD V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+
+// src/vec3.rs:12-14
+RT_HD V3 reflect(V3 v, V3 n) { return v - (n * dot(v, n)) * 2.0f; }
+
+// src/vec3.rs:16-21
+RT_HD V3 refract(V3 uv, V3 n, float etai_over_etat) {
+    float cos_theta = fminf(dot(-uv, n), 1.0f);
+    V3 r_out_perp = (uv + n * cos_theta) * etai_over_etat;
+    V3 r_out_parallel = n * -sqrtf(fabsf(1.0f - length_squared(r_out_perp)));
+    return r_out_perp + r_out_parallel;
+}
+
+RT_HD uint32_t f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+RT_HD float u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// sin / cos for the disk sampler (src/sample.rs:22).  The reference calls the platform libm through
+// f32::cos / f32::sin; on Linux that is glibc's sinf/cosf (double-precision minimax polynomials with a
+// quadrant reduction at |x| >= 0.75).  This is a restatement of that published algorithm and its
+// coefficient table; an exhaustive host-side comparison over every binary32 in [-1, 1] (the only range the
+// sampler produces) matches glibc 2.35 bit for bit, with and without fused multiply-add.  Arguments outside
+// [-1, 1] are not supported.
+// ------------------------------------------------------------------------------------------------------
+namespace sincos_detail {
+constexpr double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                 C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+constexpr double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+constexpr double HPI_INV = 0x1.45F306DC9C883p+23; // 2/pi * 2^24
+constexpr double HPI = 0x1.921FB54442D18p0;       // pi/2
+
+RT_HD uint32_t abstop12(float x) { return (f2u(x) >> 20) & 0x7ffu; }
+
+// n even: sine polynomial; n odd: cosine polynomial with its coefficients multiplied by cs (+1 / -1).
+RT_HD float poly(double x, double x2, double cs, int n) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = S2 + x2 * S3;
+        double x7 = x3 * x2;
+        double s = x + x3 * S1;
+        return (float)(s + x7 * s1);
+    }
+    double x4 = x2 * x2;
+    double c2 = cs * C3 + x2 * (cs * C4);
+    double c1 = cs * C0 + x2 * (cs * C1);
+    double x6 = x4 * x2;
+    double c = c1 + x4 * (cs * C2);
+    return (float)(c + x6 * c2);
+}
+
+// Quadrant reduction for 0.75 <= |y| <= 1: n is -1, 0 or 1.
+RT_HD double reduce(double x, int *np) {
+    double r = x * HPI_INV;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return x - n * HPI;
+}
+RT_HD double quadrant_sign(int n) { return ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0; }
+} // namespace sincos_detail
+
+RT_HD float sin_unit(float y) {
+    using namespace sincos_detail;
+    double x = y;
+    if (abstop12(y) < 0x3f4u) { // |y| < 0.75
+        if (abstop12(y) < 0x398u) return y; // |y| < 2^-12
+        return poly(x, x * x, 1.0, 0);
+    }
+    int n;
+    x = reduce(x, &n);
+    return poly(x * quadrant_sign(n), x * x, (n & 2) ? -1.0 : 1.0, n);
+}
+
+RT_HD float cos_unit(float y) {
+    using namespace sincos_detail;
+    double x = y;
+    if (abstop12(y) < 0x3f4u) {
+        if (abstop12(y) < 0x398u) return 1.0f;
+        return poly(x, x * x, 1.0, 1);
+    }
+    int n;
+    x = reduce(x, &n);
+    return poly(x * quadrant_sign(n), x * x, (n & 2) ? -1.0 : 1.0, n ^ 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Per-path random stream.  The reference draws from a thread-local SmallRng seeded from OS entropy
+// (src/random.rs:8-14), which cannot be reproduced; here draw k of path (pixel, sample) is a pure function
+// of (seed, pixel, sample, k): 64-bit block b = mix64((sample<<42 | pixel<<16 | b) * golden + mix64(seed))
+// holds draws 2b (low half) and 2b+1 (high half).  mix64 is the splitmix64 finaliser, a bijection, so
+// distinct (pixel, sample, b) never share a block.
+// ------------------------------------------------------------------------------------------------------
+RT_HD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct Rng {
+    uint64_t seed_mix; // mix64(seed)
+    uint64_t path_key; // (sample << 42) | (pixel << 16)
+    uint32_t k;        // index of the next 32-bit draw
+};
+
+RT_HD Rng rng_for_path(uint64_t seed_mix, uint32_t pixel, uint32_t sample, uint32_t k) {
+    Rng r;
+    r.seed_mix = seed_mix;
+    r.path_key = ((uint64_t)sample << 42) | ((uint64_t)(pixel & 0x3FFFFFFu) << 16);
+    r.k = k;
+    return r;
+}
+
+RT_HD uint64_t rng_block(const Rng &r, uint32_t b) {
+    uint64_t c = r.path_key | (uint64_t)(b & 0xFFFFu);
+    return mix64(c * 0x9E3779B97F4A7C15ull + r.seed_mix);
+}
+
+RT_HD uint32_t rng_next_u32(Rng &r) {
+    uint32_t k = r.k++;
+    uint64_t bits = rng_block(r, k >> 1);
+    return (k & 1u) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+}
+
+// Two consecutive draws; one block evaluation when k is even (the common case).
+RT_HD void rng_next_2u32(Rng &r, uint32_t &a, uint32_t &b) {
+    if ((r.k & 1u) == 0) {
+        uint64_t bits = rng_block(r, r.k >> 1);
+        r.k += 2;
+        a = (uint32_t)bits;
+        b = (uint32_t)(bits >> 32);
+    } else {
+        a = rng_next_u32(r);
+        b = rng_next_u32(r);
+    }
+}
+
+// rand 0.8.5 `gen::<f32>()` (src/random.rs:12-14): 24 random bits scaled by 2^-24.
+RT_HD float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+RT_HD float rng_random(Rng &r) { return u32_to_unit(rng_next_u32(r)); }
+
+// rand 0.8.5 `gen_range(lo..hi)` for f32 (src/random.rs:16-18): a [0,1) value with 23 random mantissa
+// bits, times (hi - lo), plus lo; redrawn while the result is not below hi.
+RT_HD float rng_random_range(Rng &r, float lo, float hi) {
+    float scale = hi - lo;
+    for (;;) {
+        float value1_2 = u2f((rng_next_u32(r) >> 9) | 0x3F800000u);
+        float value0_1 = value1_2 - 1.0f;
+        float res = value0_1 * scale + lo;
+        if (res < hi) return res;
+    }
+}
+
+} // namespace rt

@@ -1,0 +1,426 @@
+"""Host-side scene types mirroring the reference's `scene.rs`, `material.rs`, `texture.rs`, `camera.rs`.
+
+These are plain containers: they hold what the reference's loader produces (src/scene.rs:116-250) and know
+how to lay themselves out as the `rt_scene_desc` the C ABI consumes.  No rendering arithmetic happens here.
+"""
+from __future__ import annotations
+
+import base64
+import ctypes as C
+import json
+import math
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi as F
+
+f32 = np.float32
+
+
+# ------------------------------------------------------------------------------------------------------
+# textures / materials (src/texture.rs:140-154, src/material.rs:141-176)
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class Texture:
+    kind: int
+    rgb: Sequence[float] = (0.0, 0.0, 0.0)
+    inv_scale: float = 0.0
+    even: int = -1
+    odd: int = -1
+    image: Optional[np.ndarray] = None  # (H, W, 3) uint8
+
+    @staticmethod
+    def solid_color(rgb) -> "Texture":
+        return Texture(F.RT_TEX_SOLID, tuple(float(f32(c)) for c in rgb))
+
+    @staticmethod
+    def checkerboard(inv_scale: float, even: int, odd: int) -> "Texture":
+        return Texture(F.RT_TEX_CHECKER, inv_scale=float(inv_scale), even=even, odd=odd)
+
+    @staticmethod
+    def from_image(pixels: np.ndarray) -> "Texture":
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        assert px.ndim == 3 and px.shape[2] == 3
+        return Texture(F.RT_TEX_IMAGE, image=px)
+
+
+@dataclass
+class Material:
+    kind: int
+    texture: int = -1
+    param: float = 0.0
+    left: int = -1
+    right: int = -1
+
+
+@dataclass
+class TriangleMesh:
+    """`TriangleMeshData` (src/object/triangle_mesh.rs:12-18): transformed positions, raw normals."""
+    positions: np.ndarray  # (nv, 3) f32
+    indices: np.ndarray    # (nf, 3) u32
+    normals: np.ndarray    # (nn, 3) f32, possibly empty
+    uvs: np.ndarray        # (nuv, 2) f32, possibly empty
+    material: int
+
+
+@dataclass
+class Sphere:
+    center: Sequence[float]
+    radius: float
+    material: int
+
+
+@dataclass
+class CameraSettings:
+    """`CameraSettings` (src/scene.rs:62-85)."""
+    name: Optional[str] = None
+    y_fov: float = float(f32(80.0) * f32(math.pi / 180.0))
+    z_near: float = float(f32(0.0001))
+    z_far: float = math.inf
+    transform: np.ndarray = field(default_factory=lambda: np.array(
+        [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=f32))  # Affine3A columns: x, y, z axes, translation
+    focus_dist: float = 10.0
+    defocus_angle: float = 0.0
+
+    def to_c(self) -> F.rt_camera_settings:
+        s = F.rt_camera_settings()
+        s.y_fov, s.z_near, s.z_far = self.y_fov, self.z_near, self.z_far
+        for i, v in enumerate(np.asarray(self.transform, dtype=f32).reshape(12)):
+            s.transform[i] = float(v)
+        s.focus_dist, s.defocus_angle = self.focus_dist, self.defocus_angle
+        return s
+
+    @staticmethod
+    def look_at(look_from, look_at, y_fov_deg: float, focus_dist=10.0, defocus_angle=0.0, z_near=1e-4,
+                z_far=math.inf) -> "CameraSettings":
+        """A camera whose node transform puts the origin at `look_from` and -Z towards `look_at`.
+
+        `Camera::new` only uses the images of (0,0,0) and (0,0,-1) under the transform
+        (src/camera.rs:29-30), so any rigid frame with that -Z axis gives the same camera."""
+        lf = np.asarray(look_from, dtype=np.float64)
+        la = np.asarray(look_at, dtype=np.float64)
+        w = lf - la
+        w /= np.linalg.norm(w)
+        up = np.array([0.0, 1.0, 0.0])
+        u = np.cross(up, w)
+        u /= np.linalg.norm(u)
+        v = np.cross(w, u)
+        tr = np.concatenate([u, v, w, lf]).astype(f32)
+        return CameraSettings(None, float(f32(math.radians(y_fov_deg))), float(f32(z_near)), z_far, tr,
+                              float(focus_dist), float(defocus_angle))
+
+
+@dataclass
+class RenderSettings:
+    """`RenderSettings` (src/scene.rs:53-60) plus seed / mode / sample range (see rt_settings)."""
+    image_width: int = 1280
+    image_height: int = 720
+    selected_camera: int = 0
+    max_depth: int = 50
+    samples_per_pixel: int = 100
+    background_color: Sequence[float] = (0.0, 0.0, 0.0)
+    mode: int = F.RT_MODE_GAMMA_PER_SAMPLE
+    seed: int = 1
+    sample_begin: int = 0
+    sample_count: int = 0
+
+    def to_c(self) -> F.rt_settings:
+        s = F.rt_settings()
+        s.image_width, s.image_height = self.image_width, self.image_height
+        s.max_depth, s.samples_per_pixel = self.max_depth, self.samples_per_pixel
+        for i in range(3):
+            s.background_color[i] = float(self.background_color[i])
+        s.mode, s.seed = self.mode, self.seed & 0xFFFFFFFFFFFFFFFF
+        s.sample_begin, s.sample_count = self.sample_begin, self.sample_count
+        return s
+
+
+class SceneDescription:
+    """`SceneDescription` (src/scene.rs:18-27): the flat object list and the cameras."""
+
+    def __init__(self, meshes: List[TriangleMesh] = None, spheres: List[Sphere] = None,
+                 materials: List[Material] = None, textures: List[Texture] = None,
+                 cameras: List[CameraSettings] = None, spheres_first: bool = False):
+        self.meshes = meshes or []
+        self.spheres = spheres or []
+        self.materials = materials or []
+        self.textures = textures or []
+        self.cameras = cameras or []
+        self.spheres_first = spheres_first
+
+    def camera(self, index: int) -> CameraSettings:
+        """src/scene.rs:25-27: out-of-range selects the default camera."""
+        if 0 <= index < len(self.cameras):
+            return self.cameras[index]
+        return CameraSettings()
+
+    # -- material helpers mirroring Material::{lambertian, metal, dielectric, mix} (src/material.rs:150-176)
+    def add_texture(self, t: Texture) -> int:
+        self.textures.append(t)
+        return len(self.textures) - 1
+
+    def add_material(self, m: Material) -> int:
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def lambertian(self, albedo) -> int:
+        return self.add_material(Material(F.RT_MAT_LAMBERTIAN, self.add_texture(Texture.solid_color(albedo))))
+
+    def lambertian_texture(self, tex: int) -> int:
+        return self.add_material(Material(F.RT_MAT_LAMBERTIAN, tex))
+
+    def metal(self, albedo, fuzz: float) -> int:
+        return self.add_material(Material(F.RT_MAT_METAL, self.add_texture(Texture.solid_color(albedo)),
+                                          float(f32(fuzz))))
+
+    def dielectric(self, refraction_index: float) -> int:
+        return self.add_material(Material(F.RT_MAT_DIELECTRIC, -1, float(f32(refraction_index))))
+
+    def diffuse_light(self, rgb, strength: float) -> int:
+        return self.add_material(Material(F.RT_MAT_DIFFUSE_LIGHT, self.add_texture(Texture.solid_color(rgb)),
+                                          float(f32(strength))))
+
+    def mix(self, left: int, right: int, factor: float) -> int:
+        return self.add_material(Material(F.RT_MAT_MIX, -1, float(f32(factor)), left, right))
+
+    @property
+    def num_primitives(self) -> int:
+        return sum(len(m.indices) for m in self.meshes) + len(self.spheres)
+
+    def to_desc(self):
+        """Returns (rt_scene_desc, keepalive).  `keepalive` owns every buffer the descriptor points into."""
+        keep = []
+
+        def fptr(a):
+            a = np.ascontiguousarray(a, dtype=f32)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_float)) if a.size else None
+
+        meshes = (F.rt_mesh * max(1, len(self.meshes)))()
+        for i, m in enumerate(self.meshes):
+            idx = np.ascontiguousarray(m.indices, dtype=np.uint32)
+            keep.append(idx)
+            c = meshes[i]
+            c.num_vertices = len(m.positions)
+            c.positions = fptr(m.positions)
+            c.num_normals = len(m.normals)
+            c.normals = fptr(m.normals)
+            c.num_uvs = len(m.uvs)
+            c.uvs = fptr(m.uvs)
+            c.num_faces = len(idx)
+            c.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32)) if idx.size else None
+            c.material = m.material
+        spheres = (F.rt_sphere * max(1, len(self.spheres)))()
+        for i, s in enumerate(self.spheres):
+            for k in range(3):
+                spheres[i].center[k] = float(f32(s.center[k]))
+            spheres[i].radius = float(f32(s.radius))
+            spheres[i].material = s.material
+        mats = (F.rt_material * max(1, len(self.materials)))()
+        for i, m in enumerate(self.materials):
+            mats[i].kind, mats[i].texture, mats[i].param = m.kind, m.texture, m.param
+            mats[i].left, mats[i].right = m.left, m.right
+        texs = (F.rt_texture * max(1, len(self.textures)))()
+        for i, t in enumerate(self.textures):
+            texs[i].kind = t.kind
+            for k in range(3):
+                texs[i].rgb[k] = float(t.rgb[k])
+            texs[i].inv_scale, texs[i].even, texs[i].odd = t.inv_scale, t.even, t.odd
+            if t.image is not None:
+                keep.append(t.image)
+                texs[i].height, texs[i].width = t.image.shape[0], t.image.shape[1]
+                texs[i].pixels = t.image.ctypes.data_as(C.POINTER(C.c_uint8)) if t.image.size else None
+        d = F.rt_scene_desc()
+        d.num_meshes, d.meshes = len(self.meshes), meshes
+        d.num_spheres, d.spheres = len(self.spheres), spheres
+        d.num_materials, d.materials = len(self.materials), mats
+        d.num_textures, d.textures = len(self.textures), texs
+        d.spheres_first = 1 if self.spheres_first else 0
+        keep += [meshes, spheres, mats, texs]
+        return d, keep
+
+
+# ------------------------------------------------------------------------------------------------------
+# glTF import (src/scene.rs:116-250)
+# ------------------------------------------------------------------------------------------------------
+_COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def _node_matrix(node) -> np.ndarray:
+    """Column-major 4x4 of the node's LOCAL transform (the reference ignores the hierarchy,
+    src/scene.rs:213-216).  TRS is composed as T * R * S in binary32 like the `gltf` crate's
+    `Transform::matrix` (gltf 1.4.1, not vendored: rounding of rotated nodes is unpinned; the reference's
+    assets only translate and scale, which is exact)."""
+    if "matrix" in node:
+        return np.array(node["matrix"], dtype=f32).reshape(4, 4).T  # stored column-major
+    t = np.array(node.get("translation", [0, 0, 0]), dtype=f32)
+    q = np.array(node.get("rotation", [0, 0, 0, 1]), dtype=f32)
+    s = np.array(node.get("scale", [1, 1, 1]), dtype=f32)
+    x, y, z, w = q
+    x2, y2, z2 = x + x, y + y, z + z
+    xx2, xy2, xz2 = x2 * x, x2 * y, x2 * z
+    yy2, yz2, zz2 = y2 * y, y2 * z, z2 * z
+    sx2, sy2, sz2 = x2 * w, y2 * w, z2 * w
+    one = f32(1)
+    r = np.array([[one - yy2 - zz2, xy2 - sz2, xz2 + sy2],
+                  [xy2 + sz2, one - xx2 - zz2, yz2 - sx2],
+                  [xz2 - sy2, yz2 + sx2, one - xx2 - yy2]], dtype=f32)
+    m = np.zeros((4, 4), dtype=f32)
+    m[:3, :3] = r * s[None, :]
+    m[:3, 3] = t
+    m[3, 3] = 1
+    return m
+
+
+def _affine_from_mat4(m: np.ndarray) -> np.ndarray:
+    """glam Affine3A::from_mat4: the upper 3x4, stored x_axis, y_axis, z_axis, translation."""
+    return np.concatenate([m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3]]).astype(f32)
+
+
+def _transform_points(aff: np.ndarray, p: np.ndarray) -> np.ndarray:
+    """glam Affine3A::transform_point3a: ((x_axis*p.x + y_axis*p.y) + z_axis*p.z) + translation, binary32."""
+    xa, ya, za, tr = aff[0:3], aff[3:6], aff[6:9], aff[9:12]
+    r = xa[None, :] * p[:, 0:1]
+    r = r + ya[None, :] * p[:, 1:2]
+    r = r + za[None, :] * p[:, 2:3]
+    return (r + tr[None, :]).astype(f32)
+
+
+class _Gltf:
+    def __init__(self, path: str):
+        self.dir = os.path.dirname(os.path.abspath(path))
+        with open(path, "rb") as fh:
+            head = fh.read(4)
+            fh.seek(0)
+            raw = fh.read()
+        self.bin_chunk = None
+        if head == b"glTF":  # GLB container
+            length = int.from_bytes(raw[8:12], "little")
+            off = 12
+            doc = None
+            while off < length:
+                clen = int.from_bytes(raw[off:off + 4], "little")
+                ctype = raw[off + 4:off + 8]
+                body = raw[off + 8:off + 8 + clen]
+                if ctype == b"JSON":
+                    doc = json.loads(body.decode("utf-8"))
+                elif ctype == b"BIN\x00":
+                    self.bin_chunk = body
+                off += 8 + clen
+            self.doc = doc
+        else:
+            self.doc = json.loads(raw.decode("utf-8"))
+        self.buffers = [self._load_buffer(b) for b in self.doc.get("buffers", [])]
+
+    def _load_buffer(self, b) -> bytes:
+        uri = b.get("uri")
+        if uri is None:
+            return self.bin_chunk
+        if uri.startswith("data:"):
+            return base64.b64decode(uri.split(",", 1)[1])
+        with open(os.path.join(self.dir, uri), "rb") as fh:
+            return fh.read()
+
+    def accessor(self, index: int) -> np.ndarray:
+        a = self.doc["accessors"][index]
+        if "sparse" in a:
+            raise NotImplementedError("sparse accessors")
+        dt = np.dtype(_COMP[a["componentType"]]).newbyteorder("<")
+        ncomp = _NCOMP[a["type"]]
+        count = a["count"]
+        if "bufferView" not in a:
+            return np.zeros((count, ncomp), dtype=dt)
+        bv = self.doc["bufferViews"][a["bufferView"]]
+        data = self.buffers[bv["buffer"]]
+        start = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        elem = dt.itemsize * ncomp
+        stride = bv.get("byteStride", elem) or elem
+        if stride == elem:
+            arr = np.frombuffer(data, dtype=dt, count=count * ncomp, offset=start)
+        else:
+            base = np.frombuffer(data, dtype=np.uint8, count=(count - 1) * stride + elem, offset=start)
+            arr = np.lib.stride_tricks.as_strided(base, shape=(count, elem), strides=(stride, 1))
+            arr = np.ascontiguousarray(arr).view(dt)
+        return arr.reshape(count, ncomp)
+
+
+def _to_f32_texcoords(a: np.ndarray, accessor) -> np.ndarray:
+    if a.dtype == np.uint8:
+        return (a.astype(f32) / f32(255.0)).astype(f32)
+    if a.dtype == np.uint16:
+        return (a.astype(f32) / f32(65535.0)).astype(f32)
+    return a.astype(f32)
+
+
+def load_from_gltf(path: str, image_decoder=None) -> SceneDescription:
+    """`scene::load_from_gltf` (src/scene.rs:208-250) + `read_mesh` (src/scene.rs:116-206).
+
+    Quirks kept: every node's local transform is used as if it were global; only the first TRIANGLES
+    primitive of a mesh is read; positions are transformed, normals are not; a primitive without indices
+    yields no faces; a non-zero emissive factor makes a white DiffuseLight of the material's emissive
+    strength, anything else a Lambertian of the base colour.
+
+    `image_decoder(bytes) -> (H, W, 3) uint8` is needed only for base-colour textures."""
+    g = _Gltf(path)
+    doc = g.doc
+    scene = SceneDescription()
+    for node in doc.get("nodes", []):
+        aff = _affine_from_mat4(_node_matrix(node))
+        if "mesh" in node:
+            mesh = doc["meshes"][node["mesh"]]
+            prims = [p for p in mesh.get("primitives", []) if p.get("mode", 4) == 4]
+            if not prims:
+                raise ValueError("mesh must have at least one triangles primitive")
+            prim = prims[0]
+            mat = doc["materials"][prim["material"]] if "material" in prim else {}
+            pbr = mat.get("pbrMetallicRoughness", {})
+            emissive = [float(f32(c)) for c in mat.get("emissiveFactor", [0.0, 0.0, 0.0])]
+            if any(c != 0.0 for c in emissive):
+                strength = mat.get("extensions", {}).get("KHR_materials_emissive_strength", {}).get(
+                    "emissiveStrength", 1.0)
+                mid = scene.diffuse_light((1.0, 1.0, 1.0), strength)
+            elif "baseColorTexture" in pbr:
+                tex = doc["textures"][pbr["baseColorTexture"]["index"]]
+                img = doc["images"][tex["source"]]
+                if image_decoder is None:
+                    raise NotImplementedError("base-colour textures need an image decoder")
+                if "uri" in img:
+                    uri = img["uri"]
+                    raw = base64.b64decode(uri.split(",", 1)[1]) if uri.startswith("data:") else open(
+                        os.path.join(g.dir, uri), "rb").read()
+                else:
+                    bv = doc["bufferViews"][img["bufferView"]]
+                    raw = g.buffers[bv["buffer"]][bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
+                mid = scene.lambertian_texture(scene.add_texture(Texture.from_image(image_decoder(raw))))
+            else:
+                col = pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])
+                mid = scene.lambertian(col[:3])
+            attrs = prim.get("attributes", {})
+            positions = np.zeros((0, 3), dtype=f32)
+            if "POSITION" in attrs:
+                positions = _transform_points(aff, g.accessor(attrs["POSITION"]).astype(f32))
+            indices = np.zeros((0, 3), dtype=np.uint32)
+            if "indices" in prim:
+                flat = g.accessor(prim["indices"]).astype(np.uint32).reshape(-1)
+                indices = flat[: (len(flat) // 3) * 3].reshape(-1, 3)
+            normals = np.zeros((0, 3), dtype=f32)
+            if "NORMAL" in attrs:
+                normals = g.accessor(attrs["NORMAL"]).astype(f32)
+            uvs = np.zeros((0, 2), dtype=f32)
+            if "TEXCOORD_0" in attrs:
+                uvs = _to_f32_texcoords(g.accessor(attrs["TEXCOORD_0"]), None)
+            scene.meshes.append(TriangleMesh(np.ascontiguousarray(positions), np.ascontiguousarray(indices),
+                                             np.ascontiguousarray(normals), np.ascontiguousarray(uvs), mid))
+        if "camera" in node:
+            cam = doc["cameras"][node["camera"]]
+            if cam.get("type") == "perspective":
+                p = cam["perspective"]
+                scene.cameras.append(CameraSettings(
+                    name=cam.get("name"), y_fov=float(f32(p["yfov"])), z_near=float(f32(p["znear"])),
+                    z_far=float(f32(p["zfar"])) if "zfar" in p else math.inf, transform=aff,
+                    focus_dist=10.0, defocus_angle=0.0))
+    return scene

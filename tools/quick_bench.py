@@ -1,0 +1,46 @@
+"""Ad-hoc GPU timing of one scene: python tools/quick_bench.py [cornell|teapot] W H SPP [flags]."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+from raytracer_amd import RenderSettings, _ffi as F, load_from_gltf
+from raytracer_amd.renderer import Context, Renderer, Scene, camera_from_settings
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+    w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+    h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
+    spp = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+    flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    desc = load_from_gltf(os.path.join(ROOT, "assets", f"{name}.gltf"))
+    ctx = Context(0, flags=flags)
+    t0 = time.time()
+    scene = Scene(ctx, desc)
+    i = scene.info()
+    print(f"scene {name}: {i.num_triangles} tris, {i.num_nodes} nodes, depth {i.depth}, build+upload {time.time()-t0:.3f}s")
+    cam = camera_from_settings(desc.camera(0), w, h)
+    rs = RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=1)
+    r = Renderer(cam, scene, rs)
+    for rep in range(3):
+        t0 = time.time()
+        img = r.render_sums()
+        dt = time.time() - t0
+        st = r.last_stats
+        print(f"rep {rep}: wall {dt*1e3:.1f} ms, gpu {st.total_ms:.1f} ms, rays {st.rays_traced} paths {st.paths} "
+              f"rays/path {st.rays_traced/st.paths:.3f} -> {st.rays_traced/st.total_ms/1e3:.1f} Mrays/s; "
+              f"gen {st.generate_ms:.2f} ext {st.extend_ms:.2f} shade {st.shade_ms:.2f} acc {st.accumulate_ms:.2f} ms; "
+              f"nodes/ray {st.node_visits/max(1,st.rays_traced):.2f} tri/ray {st.triangle_tests/max(1,st.rays_traced):.2f}")
+    img /= spp
+    fin = np.isfinite(img)
+    print(f"nan {np.isnan(img).mean():.4f} inf {np.isinf(img).mean():.4f} mean(finite) {img[fin].mean():.5f}")
+
+
+if __name__ == "__main__":
+    main()
