@@ -60,6 +60,7 @@ def _check(code: int) -> None:
 
 class OracleScene:
     def __init__(self, scene):
+        self.handle = None
         d, self._keep = scene.to_desc()
         h = C.c_void_p()
         _check(lib().oracle_scene_create(C.byref(d), C.byref(h)))

@@ -149,6 +149,14 @@ def load_library(path: str | None = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch-ROCm wheels bundle their own HIP runtime (libamdhip64.so.7).  Two HIP runtimes in one process
+    # cannot both own the GPU, so when torch is installed it is imported FIRST: the dynamic loader then
+    # satisfies this library's libamdhip64.so.7 dependency with the copy torch already mapped (same SONAME)
+    # and torch tensors, streams and RCCL share one runtime with the renderer.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise ImportError(
             f"{p} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')"

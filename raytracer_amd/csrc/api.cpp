@@ -80,12 +80,13 @@ struct rt_context {
     // wavefront workspace
     DevBuf<float4> ray_o, ray_d, hit, beta, radiance;
     DevBuf<uint32_t> queue[2];
-    DevBuf<uint32_t> counts;
+    DevBuf<uint32_t> counts;              // [max_depth + 1][grid] survivors per block and bounce
+    DevBuf<unsigned long long> totals;    // [max_depth + 1] per-bounce sums of `counts`
     DevBuf<rt::ExtendCounters> counters;
     DevBuf<float> accum;     // rt_render's device image
     DevBuf<float> ray_stage; // rt_trace_closest's device copies
     DevBuf<uint32_t> hit_stage;
-    uint32_t *host_counts = nullptr; // pinned
+    unsigned long long *host_counts = nullptr; // pinned
     size_t host_counts_cap = 0;
 
     // timing
@@ -118,13 +119,14 @@ int ensure_paths(rt_context *c, size_t n) {
     return RT_OK;
 }
 
-int ensure_render(rt_context *c, size_t n, uint32_t max_depth) {
+int ensure_render(rt_context *c, size_t n, size_t queue_len, uint32_t max_depth, uint32_t grid) {
     if (int rc = ensure_paths(c, n)) return rc;
     if (int rc = c->beta.ensure(n)) return rc;
     if (int rc = c->radiance.ensure(n)) return rc;
-    if (int rc = c->queue[0].ensure(n)) return rc;
-    if (int rc = c->queue[1].ensure(n)) return rc;
-    if (int rc = c->counts.ensure((size_t)max_depth + 2)) return rc;
+    if (int rc = c->queue[0].ensure(queue_len)) return rc;
+    if (int rc = c->queue[1].ensure(queue_len)) return rc;
+    if (int rc = c->counts.ensure(((size_t)max_depth + 1) * grid)) return rc;
+    if (int rc = c->totals.ensure((size_t)max_depth + 1)) return rc;
     if (int rc = c->counters.ensure(1)) return rc;
     return RT_OK;
 }
@@ -134,7 +136,8 @@ int ensure_host_counts(rt_context *c, size_t n) {
     if (c->host_counts) HIP_TRY(hipHostFree(c->host_counts));
     c->host_counts = nullptr;
     c->host_counts_cap = 0;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->host_counts), n * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->host_counts), n * sizeof(unsigned long long),
+                          hipHostMallocDefault));
     c->host_counts_cap = n;
     return RT_OK;
 }
@@ -255,6 +258,7 @@ RT_API int rt_context_destroy(rt_context *c) {
     c->queue[0].release();
     c->queue[1].release();
     c->counts.release();
+    c->totals.release();
     c->counters.release();
     c->accum.release();
     c->ray_stage.release();
@@ -444,8 +448,10 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     rt::launch_pack_rays(c->stream, c->max_blocks, reinterpret_cast<const float *>(d_rays), (uint32_t)n, c->ray_o.ptr,
                          c->ray_d.ptr);
     if (int rc = timed_begin(c, K_EXTEND)) return rc;
-    rt::launch_extend(c->stream, c->max_blocks, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, nullptr, nullptr,
-                      (uint32_t)n, t_min, t_max, use_bvh != 0, count ? c->counters.ptr : nullptr);
+    const rt::QueueView all{nullptr, nullptr, 0u, (uint32_t)n};
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(c->max_blocks, (n + 255) / 256);
+    rt::launch_extend(c->stream, grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, all, t_min, t_max, use_bvh != 0,
+                      count ? c->counters.ptr : nullptr);
     if (int rc = timed_end(c)) return rc;
     rt::launch_finalize_hits(c->stream, c->max_blocks, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, d_out);
     HIP_TRY(hipGetLastError());
@@ -512,9 +518,13 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const uint32_t B = (uint32_t)per_batch;
     const size_t slots = (size_t)B * npix;
     if (slots > 0x7FFFFFFFull) return set_error(RT_ERR_INVALID_ARGUMENT, "batch exceeds 2^31 paths");
-    if (int rc = ensure_render(c, slots, st->max_depth)) return rc;
+    // One grid for every bounce of a batch: block b owns segment b of both queues (see QueueView).
+    const uint32_t chunks = (uint32_t)((slots + 255) / 256);
+    const uint32_t grid = std::min(c->max_blocks, chunks);
+    const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
+    if (int rc = ensure_render(c, slots, (size_t)grid * cap, st->max_depth, grid)) return rc;
     const uint32_t n_batches = (total + B - 1) / B;
-    const size_t counts_len = (size_t)st->max_depth + 2;
+    const size_t counts_len = (size_t)st->max_depth + 1;
     if (stats)
         if (int rc = ensure_host_counts(c, counts_len * n_batches)) return rc;
 
@@ -550,20 +560,20 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         const uint32_t n = b * npix;
         P.sample_base = st->sample_begin + s0;
         P.batch_samples = b;
-        HIP_TRY(hipMemsetAsync(c->counts.ptr, 0, counts_len * sizeof(uint32_t), c->stream));
         if (int rc = timed_begin(c, K_GENERATE)) return rc;
         rt::launch_generate(c->stream, c->max_blocks, P, ps, n);
         if (int rc = timed_end(c)) return rc;
         for (uint32_t it = 0; it < st->max_depth; ++it) {
-            const uint32_t *q_in = it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr;
-            const uint32_t *cnt_in = it == 0 ? nullptr : c->counts.ptr + it;
+            // bounce `it` consumes queue (it-1)&1 with the per-block counts of row `it`, and produces queue it&1
+            // with row it+1; bounce 0 consumes the identity queue.
+            rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
             if (int rc = timed_begin(c, K_EXTEND)) return rc;
-            rt::launch_extend(c->stream, c->max_blocks, s->dev, ps.ray_o, ps.ray_d, ps.hit, q_in, cnt_in, n, cam->z_near,
-                              cam->z_far, true, count ? c->counters.ptr : nullptr);
+            rt::launch_extend(c->stream, grid, s->dev, ps.ray_o, ps.ray_d, ps.hit, q, cam->z_near, cam->z_far, true,
+                              count ? c->counters.ptr : nullptr);
             if (int rc = timed_end(c)) return rc;
             if (int rc = timed_begin(c, K_SHADE)) return rc;
-            rt::launch_shade(c->stream, c->max_blocks, s->dev, P, ps, q_in, cnt_in, n, c->queue[it & 1].ptr,
-                             c->counts.ptr + it + 1, s->need_uv);
+            rt::launch_shade(c->stream, grid, s->dev, P, ps, q, c->queue[it & 1].ptr,
+                             c->counts.ptr + (size_t)(it + 1) * grid, s->need_uv);
             if (int rc = timed_end(c)) return rc;
             ++extend_launches;
             ++shade_launches;
@@ -571,9 +581,11 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         if (int rc = timed_begin(c, K_ACCUMULATE)) return rc;
         rt::launch_accumulate(c->stream, c->max_blocks, P, ps.radiance, d_accum);
         if (int rc = timed_end(c)) return rc;
-        if (stats)
-            HIP_TRY(hipMemcpyAsync(c->host_counts + counts_len * bi, c->counts.ptr, counts_len * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, c->stream));
+        if (stats && st->max_depth > 1) {
+            rt::launch_sum_counts(c->stream, c->counts.ptr + grid, grid, st->max_depth - 1, c->totals.ptr + 1);
+            HIP_TRY(hipMemcpyAsync(c->host_counts + counts_len * bi, c->totals.ptr,
+                                   counts_len * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        }
     }
     HIP_TRY(hipGetLastError());
     if (stats) {

@@ -7,20 +7,23 @@
 
 namespace rt {
 
-// Every launcher enqueues on `s` and returns immediately.  `max_blocks` caps the persistent grid; queues
-// longer than the grid are covered by grid-stride loops.  `count_ptr`, when non-null, points at the queue
-// length in device memory and `count_bound` is only an upper bound used to size the grid; when null,
-// `count_bound` is the exact length.
+// Every launcher enqueues on `s` and returns immediately.  `max_blocks` caps the grid of the kernels that run
+// plain grid-stride loops.  extend and shade walk a segmented queue (QueueView, rt_device.h) and must be
+// launched with the same `grid` for every bounce of a batch.
 
 void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const PathState &st, uint32_t n_slots);
 
-void launch_extend(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
-                   float4 *hits, const uint32_t *queue, const uint32_t *count_ptr, uint32_t count_bound, float tmin,
-                   float tmax, bool use_bvh, ExtendCounters *counters);
+void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
+                   float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters);
 
-void launch_shade(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                  const uint32_t *queue_in, const uint32_t *count_ptr, uint32_t count_bound, uint32_t *queue_out,
-                  uint32_t *count_out, bool need_uv);
+// Shades the items of `q`; block b appends its surviving slots at queue_out[b * q.cap ...] and stores their
+// number in counts_out[b].
+void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
+                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv);
+
+// totals[r] = sum of counts[r * n_blocks .. (r + 1) * n_blocks) for r in [0, n_rows).
+void launch_sum_counts(hipStream_t s, const uint32_t *counts, uint32_t n_blocks, uint32_t n_rows,
+                       unsigned long long *totals);
 
 void launch_accumulate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const float4 *radiance, float *accum);
 

@@ -146,10 +146,6 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
     return best;
 }
 
-__device__ __forceinline__ uint32_t queue_count(const uint32_t *count_ptr, uint32_t count_imm) {
-    return count_ptr ? *count_ptr : count_imm;
-}
-
 // ------------------------------------------------------------------------------------------------------
 // surface reconstruction and materials
 // ------------------------------------------------------------------------------------------------------
@@ -403,28 +399,67 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams P, PathState s
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Queues.  A queue is segmented by workgroup: block b owns entries [b * cap, b * cap + counts[b]).  A block
+// appends the survivors of its own items to its own segment of the output queue, so compaction needs no
+// global atomic (one returning atomic per wave on a single word serialises the whole chip) and the same
+// grid must be used for every launch of a batch.  `items == nullptr` is the identity queue over [0, n): its
+// 256-item chunks are dealt to the blocks round-robin, which keeps the first bounce fully coalesced and gives
+// every block an even sample of the image.
+// ------------------------------------------------------------------------------------------------------
+struct QueueCursor {
+    uint32_t off, limit, stride, seg;
+    bool ident;
+};
+
+__device__ __forceinline__ QueueCursor queue_begin(const QueueView &q) {
+    QueueCursor c;
+    c.ident = q.items == nullptr;
+    c.limit = c.ident ? q.n : q.counts[blockIdx.x];
+    c.stride = c.ident ? gridDim.x * kBlock : kBlock;
+    c.off = c.ident ? blockIdx.x * kBlock : 0u;
+    c.seg = blockIdx.x * q.cap;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // extend: closest hit of every queued ray
 // ------------------------------------------------------------------------------------------------------
 template <bool COUNT, bool USE_BVH>
 __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__restrict__ ray_o,
                                                    const float4 *__restrict__ ray_d, float4 *__restrict__ hits,
-                                                   const uint32_t *__restrict__ queue, const uint32_t *count_ptr,
-                                                   uint32_t count_imm, float tmin, float tmax,
-                                                   ExtendCounters *counters) {
-    const uint32_t count = queue_count(count_ptr, count_imm);
+                                                   QueueView q, float tmin, float tmax, ExtendCounters *counters) {
     uint32_t c_nodes = 0, c_tri = 0, c_sph = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
-        uint32_t slot = queue ? queue[i] : i;
+    QueueCursor c = queue_begin(q);
+    for (uint32_t off = c.off; off < c.limit; off += c.stride) {
+        const uint32_t i = off + threadIdx.x;
+        if (i >= c.limit) break;
+        uint32_t slot = c.ident ? i : q.items[c.seg + i];
         V3 o = xyz(ray_o[slot]);
         V3 d = xyz(ray_d[slot]);
         Closest best = USE_BVH ? traverse<COUNT>(sc, o, d, tmin, tmax, c_nodes, c_tri, c_sph)
                                : scan_world(sc, o, d, tmin, tmax);
         hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
     }
-    if (COUNT) {
-        atomicAdd(&counters->node_visits, (unsigned long long)c_nodes);
-        atomicAdd(&counters->triangle_tests, (unsigned long long)c_tri);
-        atomicAdd(&counters->sphere_tests, (unsigned long long)c_sph);
+    if (COUNT) { // one atomic per block and counter, skipped when the block saw no work
+        __shared__ unsigned int s_cnt[3];
+        if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            c_nodes += __shfl_down(c_nodes, sh);
+            c_tri += __shfl_down(c_tri, sh);
+            c_sph += __shfl_down(c_sph, sh);
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            if (c_nodes) atomicAdd(&s_cnt[0], c_nodes);
+            if (c_tri) atomicAdd(&s_cnt[1], c_tri);
+            if (c_sph) atomicAdd(&s_cnt[2], c_sph);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (s_cnt[0]) atomicAdd(&counters->node_visits, (unsigned long long)s_cnt[0]);
+            if (s_cnt[1]) atomicAdd(&counters->triangle_tests, (unsigned long long)s_cnt[1]);
+            if (s_cnt[2]) atomicAdd(&counters->sphere_tests, (unsigned long long)s_cnt[2]);
+        }
     }
 }
 
@@ -432,20 +467,20 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
 // shade: the body of Renderer::ray_color's loop after `world.hit` (src/renderer.rs:46-66)
 // ------------------------------------------------------------------------------------------------------
 template <bool NEED_UV>
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, PathState st,
-                                                  const uint32_t *__restrict__ queue_in, const uint32_t *count_ptr,
-                                                  uint32_t count_imm, uint32_t *__restrict__ queue_out,
-                                                  uint32_t *count_out) {
-    const uint32_t count = queue_count(count_ptr, count_imm);
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, PathState st, QueueView q,
+                                                  uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out) {
+    __shared__ uint32_t s_out;
+    if (threadIdx.x == 0) s_out = 0u;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t stride = gridDim.x * kBlock;
+    QueueCursor c = queue_begin(q);
     // Whole waves iterate together so that the ballot below always sees all 64 lanes.
-    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < count; base += stride) {
-        const uint32_t i = base + lane;
+    for (uint32_t off = c.off; off < c.limit; off += c.stride) {
+        const uint32_t i = off + threadIdx.x;
         bool alive = false;
         uint32_t slot = 0;
-        if (i < count) {
-            slot = queue_in ? queue_in[i] : i;
+        if (i < c.limit) {
+            slot = c.ident ? i : q.items[c.seg + i];
             float4 h = st.hit[slot];
             float4 o4 = st.ray_o[slot];
             float4 d4 = st.ray_d[slot];
@@ -486,17 +521,32 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
             }
             st.radiance[slot] = mk4(l, 0.0f);
         }
-        // Queue compaction: one atomic per wave, lanes ranked by ballot + popcount.
+        // Queue compaction: lanes ranked by ballot + popcount, one LDS atomic per wave.
         unsigned long long mask = __ballot(alive);
         if (mask) {
             uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
             uint32_t total = __popcll(mask);
             uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(count_out, total);
+            if (lane == 0) start = atomicAdd(&s_out, total);
             start = __shfl(start, 0);
-            if (alive) queue_out[start + rank] = slot;
+            if (alive) queue_out[c.seg + start + rank] = slot;
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) counts_out[blockIdx.x] = s_out;
+}
+
+// Per-bounce ray totals of a batch: totals[it] = sum over blocks of counts[it * n_blocks + b].
+__global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ counts, uint32_t n_blocks,
+                                                       unsigned long long *__restrict__ totals) {
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0ull;
+    __syncthreads();
+    unsigned long long acc = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += kBlock) acc += counts[(size_t)blockIdx.x * n_blocks + b];
+    atomicAdd(&s_sum, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) totals[blockIdx.x] = s_sum;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -573,31 +623,29 @@ void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, 
     hipLaunchKernelGGL(k_generate, dim3(grid_for(n_slots, max_blocks)), dim3(kBlock), 0, s, P, st, n_slots);
 }
 
-void launch_extend(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
-                   float4 *hits, const uint32_t *queue, const uint32_t *count_ptr, uint32_t count_bound, float tmin,
-                   float tmax, bool use_bvh, ExtendCounters *counters) {
-    dim3 g(grid_for(count_bound, max_blocks)), b(kBlock);
-    uint32_t imm = count_ptr ? 0u : count_bound;
+void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
+                   float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters) {
+    dim3 g(grid), b(kBlock);
     if (!use_bvh)
-        hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, sc, ray_o, ray_d, hits, queue, count_ptr, imm, tmin, tmax,
-                           counters);
+        hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
     else if (counters)
-        hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, sc, ray_o, ray_d, hits, queue, count_ptr, imm, tmin, tmax,
-                           counters);
+        hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
     else
-        hipLaunchKernelGGL((k_extend<false, true>), g, b, 0, s, sc, ray_o, ray_d, hits, queue, count_ptr, imm, tmin, tmax,
-                           counters);
+        hipLaunchKernelGGL((k_extend<false, true>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
 }
 
-void launch_shade(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                  const uint32_t *queue_in, const uint32_t *count_ptr, uint32_t count_bound, uint32_t *queue_out,
-                  uint32_t *count_out, bool need_uv) {
-    dim3 g(grid_for(count_bound, max_blocks)), b(kBlock);
-    uint32_t imm = count_ptr ? 0u : count_bound;
+void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
+                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv) {
+    dim3 g(grid), b(kBlock);
     if (need_uv)
-        hipLaunchKernelGGL((k_shade<true>), g, b, 0, s, sc, P, st, queue_in, count_ptr, imm, queue_out, count_out);
+        hipLaunchKernelGGL((k_shade<true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
     else
-        hipLaunchKernelGGL((k_shade<false>), g, b, 0, s, sc, P, st, queue_in, count_ptr, imm, queue_out, count_out);
+        hipLaunchKernelGGL((k_shade<false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+}
+
+void launch_sum_counts(hipStream_t s, const uint32_t *counts, uint32_t n_blocks, uint32_t n_rows,
+                       unsigned long long *totals) {
+    hipLaunchKernelGGL(k_sum_counts, dim3(n_rows), dim3(kBlock), 0, s, counts, n_blocks, totals);
 }
 
 void launch_accumulate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const float4 *radiance, float *accum) {

@@ -127,6 +127,15 @@ struct PathState {
     float4 *radiance;
 };
 
+// A queue of path slots segmented by workgroup: block b owns items[b * cap .. b * cap + counts[b]).
+// items == nullptr denotes the identity queue over [0, n).
+struct QueueView {
+    const uint32_t *items;
+    const uint32_t *counts;
+    uint32_t cap;
+    uint32_t n;
+};
+
 struct ExtendCounters {
     unsigned long long node_visits;
     unsigned long long triangle_tests;

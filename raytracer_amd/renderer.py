@@ -18,6 +18,7 @@ class Context:
     """One GPU + one stream (rt_context)."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None, flags: int = 0):
+        self.handle = None
         self.lib = F.load_library()
         h = C.c_void_p()
         F.check(self.lib, self.lib.rt_context_create(device, C.c_void_p(stream or 0), flags, C.byref(h)))
@@ -46,6 +47,7 @@ class Scene:
     """A scene after `build_bvh` (src/scene.rs:29-49), resident in HBM (rt_scene)."""
 
     def __init__(self, ctx: Context, description: SceneDescription):
+        self.handle = None
         self.ctx = ctx
         self.lib = ctx.lib
         desc, keep = description.to_desc()

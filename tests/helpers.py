@@ -55,3 +55,45 @@ def assert_hits_equal(got, want):
         ok = bits_equal(got[f], want[f])
         assert ok.all(), f"field {f}: {np.count_nonzero(~ok)} values differ"
     assert np.array_equal(got["front_facing"], want["front_facing"])
+
+
+def scene_triangles(desc):
+    """(n, 3, 3) float64 vertices of every triangle in primitive-ID order (meshes in order, spheres excluded)."""
+    tris = []
+    for m in desc.meshes:
+        tris.append(m.positions.astype(np.float64)[m.indices.astype(np.int64)])
+    return np.concatenate(tris, axis=0) if tris else np.zeros((0, 3, 3))
+
+
+def brute_force_f64(desc, rays, t_min, t_max, rel_tie=1e-6):
+    """Independent float64 closest-hit over all triangles (Möller–Trumbore, no culling, edges inclusive).
+
+    Returns (t, candidates): t[i] is the closest distance (inf on a miss) and candidates[i] the set of
+    primitive IDs whose distance is within rel_tie of it (more than one on shared edges)."""
+    tri = scene_triangles(desc)
+    o = rays["origin"].astype(np.float64)
+    d = rays["direction"].astype(np.float64)
+    v0 = tri[:, 0][None]
+    e1 = (tri[:, 1] - tri[:, 0])[None]
+    e2 = (tri[:, 2] - tri[:, 0])[None]
+    p = np.cross(d[:, None, :], e2)
+    det = (e1 * p).sum(-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / det
+        tv = o[:, None, :] - v0
+        u = (tv * p).sum(-1) * inv
+        q = np.cross(tv, e1)
+        v = (d[:, None, :] * q).sum(-1) * inv
+        t = (e2 * q).sum(-1) * inv
+    eps = 1e-9
+    ok = (np.abs(det) > 1e-12) & (u >= -eps) & (u <= 1 + eps) & (v >= -eps) & (u + v <= 1 + eps)
+    ok &= (t >= t_min) & (t <= t_max)
+    t = np.where(ok, t, np.inf)
+    best = t.min(axis=1)
+    cands = []
+    for i in range(len(rays)):
+        if not np.isfinite(best[i]):
+            cands.append(set())
+        else:
+            cands.append(set(np.nonzero(np.abs(t[i] - best[i]) <= rel_tie * max(1.0, abs(best[i])))[0].tolist()))
+    return best, cands

@@ -1,0 +1,162 @@
+"""CPU tests of the host side: glTF import, the C-ABI surface, camera construction, device math on the host."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from raytracer_amd import CameraSettings, RenderSettings, _ffi as F
+from raytracer_amd.renderer import camera_from_settings, pixels_to_rgb8, should_save_image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gltf_cornell(cornell):
+    """assets/cornell.gltf as src/scene.rs:208-250 reads it: 6 mesh nodes, 36 triangles, 1 camera; the light
+    becomes a white DiffuseLight of strength 200, everything else Lambertian of the base colour."""
+    assert len(cornell.meshes) == 6 and cornell.num_primitives == 36
+    assert [len(m.indices) for m in cornell.meshes] == [6, 2, 2, 2, 12, 12]
+    kinds = [cornell.materials[m.material].kind for m in cornell.meshes]
+    assert kinds == [F.RT_MAT_LAMBERTIAN] * 3 + [F.RT_MAT_DIFFUSE_LIGHT] + [F.RT_MAT_LAMBERTIAN] * 2
+    light = cornell.materials[cornell.meshes[3].material]
+    assert light.param == 200.0 and tuple(cornell.textures[light.texture].rgb) == (1.0, 1.0, 1.0)
+    green = cornell.textures[cornell.materials[cornell.meshes[1].material].texture].rgb
+    assert np.allclose(green, (0.0, 0.8003553152084351, 0.000760709575843066))
+    # node transform applied to positions (scale then translate), normals untouched
+    lp = cornell.meshes[3].positions
+    assert np.allclose(lp[:, 1], 0.9856827259063721) and np.allclose(np.abs(lp[:, [0, 2]]), 0.2685281038284302)
+    assert np.allclose(np.linalg.norm(cornell.meshes[4].normals, axis=1), 1.0)
+    bb = cornell.meshes[4].positions
+    assert np.allclose(bb.min(0), [-0.4772908, -1.0027841, -0.4259056], atol=1e-6)
+    cam = cornell.cameras[0]
+    assert cam.y_fov == pytest.approx(0.691111147403717) and cam.z_far == 1000.0
+    assert cam.focus_dist == 10.0 and cam.defocus_angle == 0.0
+    assert np.allclose(cam.transform[9:], [0, 0, 3.7833845615386963])
+    assert all(len(m.uvs) == len(m.positions) for m in cornell.meshes)
+
+
+def test_gltf_teapot(teapot):
+    """assets/teapot.gltf: base64 buffer, u16 indices, normals but no uvs, node scale 10, no camera."""
+    assert len(teapot.meshes) == 1 and teapot.num_primitives == 9128
+    m = teapot.meshes[0]
+    assert m.positions.shape == (4690, 3) and m.normals.shape == (4690, 3) and m.uvs.shape == (0, 2)
+    assert np.allclose(m.positions.max(0), [33.942089, 14.2828, 20.0], atol=1e-4)
+    assert teapot.cameras == []
+    d = teapot.camera(0)  # falls back to CameraSettings::default (src/scene.rs:25-27,73-85)
+    assert d.y_fov == pytest.approx(np.float32(80.0) * np.float32(np.pi / 180)) and np.isinf(d.z_far)
+    assert teapot.materials[m.material].kind == F.RT_MAT_LAMBERTIAN
+    assert tuple(teapot.textures[teapot.materials[m.material].texture].rgb) == (1.0, 1.0, 1.0)
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/rt_mi355x.h declares is exported by the built library and bound by _ffi."""
+    text = open(os.path.join(ROOT, "include", "rt_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text))
+    assert declared == set(F.EXPORTS), declared ^ set(F.EXPORTS)
+    lib = F.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    nm = subprocess.run(["nm", "-D", "--defined-only", F.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (rt_[a-z_0-9]+)", nm))
+    assert exported == declared, exported ^ declared
+
+
+def test_struct_layouts_match_the_header():
+    """sizeof / offsets as a C compiler sees the header."""
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "rt_mi355x.h"
+    int main(void){
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rt_texture), sizeof(rt_material),
+        sizeof(rt_mesh), sizeof(rt_sphere), sizeof(rt_scene_desc), sizeof(rt_scene_info), sizeof(rt_camera_settings),
+        sizeof(rt_camera), sizeof(rt_settings), sizeof(rt_ray), sizeof(rt_hit), sizeof(rt_stats));
+      printf("%zu %zu %zu\n", offsetof(rt_settings, seed), offsetof(rt_stats, total_ms), offsetof(rt_mesh, material));
+      return 0; }'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "l.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "l")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True).stdout.split()
+    sizes = [C.sizeof(t) for t in (F.rt_texture, F.rt_material, F.rt_mesh, F.rt_sphere, F.rt_scene_desc,
+                                   F.rt_scene_info, F.rt_camera_settings, F.rt_camera, F.rt_settings, F.rt_ray,
+                                   F.rt_hit, F.rt_stats)]
+    assert [int(x) for x in out[:12]] == sizes
+    assert [int(x) for x in out[12:]] == [F.rt_settings.seed.offset, F.rt_stats.total_ms.offset,
+                                          F.rt_mesh.material.offset]
+    assert np.dtype(F.RAY_DTYPE).itemsize == C.sizeof(F.rt_ray)
+    assert np.dtype(F.HIT_DTYPE).itemsize == C.sizeof(F.rt_hit)
+
+
+def test_camera_matches_oracle_and_hand_values(cornell):
+    """rt_camera_from_settings (host code of the product) == the oracle's Camera::new, bit for bit, and the
+    Cornell camera has the hand-derived geometry: centre (0,0,3.78), |pixel delta| = 2*tan(yfov/2)*10/H."""
+    for cs, (w, h) in ((cornell.camera(0), (600, 600)), (cornell.camera(0), (1920, 1080)),
+                       (CameraSettings(), (1280, 720)),
+                       (CameraSettings.look_at((13, 2, 3), (0, 0, 0), 20.0, defocus_angle=0.6), (400, 225))):
+        a = camera_from_settings(cs, w, h)
+        b = ob.camera_from_settings(cs, w, h)
+        assert bytes(a) == bytes(b)
+    cam = camera_from_settings(cornell.camera(0), 600, 600)
+    assert list(cam.center) == [0.0, 0.0, np.float32(3.7833845615386963)]
+    expect = 2 * np.tan(0.691111147403717 / 2) * 10 / 600
+    assert cam.pixel_delta_u[0] == pytest.approx(expect, rel=1e-6) and cam.pixel_delta_v[1] == pytest.approx(-expect, rel=1e-6)
+    assert cam.pixel_00_loc[2] == pytest.approx(3.7833845615386963 - 10, rel=1e-6)
+    assert cam.defocus_disk_u[0] == 0.0 and cam.z_near == np.float32(0.1)
+    lib = F.load_library()
+    assert lib.rt_camera_from_settings(None, 1, 1, None) == F.RT_ERR_INVALID_ARGUMENT
+    s = cornell.camera(0).to_c()
+    out = F.rt_camera()
+    assert lib.rt_camera_from_settings(C.byref(s), 0, 10, C.byref(out)) == F.RT_ERR_INVALID_ARGUMENT
+    assert b"non-zero" in lib.rt_last_error()
+
+
+def test_device_sincos_matches_libm_on_host():
+    """rt::sin_unit / rt::cos_unit, compiled for the host from the same header the kernels include, equal
+    glibc's sinf / cosf bit for bit on [-1, 1] (every 61st binary32 plus the switch points exhaustively; the
+    full exhaustive sweep, 2^31 values, also reports zero mismatches)."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "sincos_check")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+                               os.path.join(ROOT, "tests", "native", "sincos_check.cpp"), "-o", exe, "-lm"])
+        out = subprocess.run([exe, "61"], capture_output=True, text=True, check=True).stdout.split()
+    checked, bad_s, bad_c = (int(x) for x in out)
+    assert checked > 3.4e7 and bad_s == 0 and bad_c == 0
+
+
+def test_product_fails_loudly_without_a_gpu():
+    """No CPU fallback: without a HIP device a context cannot be created and the error says so."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = F.load_library()
+    h = C.c_void_p()
+    rc = lib.rt_context_create(0, None, 0, C.byref(h))
+    assert rc == F.RT_ERR_NO_DEVICE and not h.value
+    assert b"no CPU path" in lib.rt_last_error() or b"no HIP device" in lib.rt_last_error()
+    with pytest.raises(ImportError):
+        F.load_library("/nonexistent/librt_mi355x.so")
+
+
+def test_progressive_schedule_and_rgb8():
+    """should_save_image (src/renderer.rs:167-171) and the f32 -> u8 conversion of pixels_to_image."""
+    saved = [s for s in range(1, 101) if should_save_image(s, 100)]
+    assert saved == [1, 2, 3, 4, 5, 16, 32, 48, 64, 80, 96, 100]
+    px = np.array([0.0, 0.5, 1.0, 2.0, -1.0, np.nan, np.inf], dtype=np.float32)
+    assert pixels_to_rgb8(px).tolist() == [0, 128, 255, 255, 0, 0, 255]
+
+
+def test_render_settings_defaults_match_cli():
+    """Defaults of the reference CLI (src/main.rs:46-59,86): 1280x720, depth 50, 100 spp, black background."""
+    rs = RenderSettings()
+    assert (rs.image_width, rs.image_height, rs.max_depth, rs.samples_per_pixel) == (1280, 720, 50, 100)
+    assert tuple(rs.background_color) == (0.0, 0.0, 0.0)
+    c = rs.to_c()
+    assert c.mode == F.RT_MODE_GAMMA_PER_SAMPLE and c.seed == 1
