@@ -224,10 +224,13 @@ typedef struct rt_stats {
     uint32_t extend_launches;
     uint32_t shade_launches;
     double total_ms;      /* GPU time of the whole call, HIP events on the context's stream */
-    double generate_ms;   /* per-kernel sums; only filled when the context has RT_CTX_TIMING */
+    double generate_ms;   /* per-kernel sums over the timed launches; need RT_CTX_TIMING */
     double extend_ms;
     double shade_ms;
     double accumulate_ms;
+    uint64_t timed_extend_rays;     /* rays processed by the extend launches that extend_ms covers */
+    uint32_t timed_extend_launches; /* number of those launches */
+    uint32_t reserved;
 } rt_stats;
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -257,6 +260,9 @@ int rt_context_destroy(rt_context *ctx);
 int rt_context_synchronize(rt_context *ctx);
 /* Upper bound on concurrently traced paths (slots of wavefront state).  0 restores the default. */
 int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
+/* With RT_CTX_TIMING, bracket only the launches of the first `bounces` bounces of every batch with events
+ * (the later bounces of a batch carry a vanishing share of the rays but most of the launches).  0 = all. */
+int rt_context_set_timed_bounces(rt_context *ctx, uint32_t bounces);
 
 /* `SceneDescription` after `build_bvh(BvhType::Tree)` (src/scene.rs:29-49, src/main.rs:91): validates the
  * description, builds the BVH on the host by the reference's rule (src/bvh.rs:248-285, src/aabb.rs:26-93,

@@ -98,7 +98,9 @@ class rt_stats(C.Structure):
                 ("triangle_tests", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32),
                 ("total_ms", C.c_double), ("generate_ms", C.c_double), ("extend_ms", C.c_double),
-                ("shade_ms", C.c_double), ("accumulate_ms", C.c_double)]
+                ("shade_ms", C.c_double), ("accumulate_ms", C.c_double),
+                ("timed_extend_rays", C.c_uint64), ("timed_extend_launches", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 # numpy dtypes with the same layout as rt_ray / rt_hit (both are 4-byte-aligned plain records).
@@ -115,6 +117,7 @@ EXPORTS = {
     "rt_context_destroy": (C.c_int, [_vp]),
     "rt_context_synchronize": (C.c_int, [_vp]),
     "rt_context_set_max_paths": (C.c_int, [_vp, C.c_uint64]),
+    "rt_context_set_timed_bounces": (C.c_int, [_vp, C.c_uint32]),
     "rt_scene_create": (C.c_int, [_vp, C.POINTER(rt_scene_desc), C.POINTER(_vp)]),
     "rt_scene_destroy": (C.c_int, [_vp]),
     "rt_scene_get_info": (C.c_int, [_vp, C.POINTER(rt_scene_info)]),

@@ -76,6 +76,7 @@ struct rt_context {
     uint32_t flags = 0;
     uint32_t max_blocks = 2048;
     uint64_t max_paths = 1ull << 24;
+    uint32_t timed_bounces = 0xFFFFFFFFu;
 
     // wavefront workspace
     DevBuf<float4> ray_o, ray_d, hit, beta, radiance;
@@ -142,8 +143,8 @@ int ensure_host_counts(rt_context *c, size_t n) {
     return RT_OK;
 }
 
-int timed_begin(rt_context *c, int kind) {
-    if (!(c->flags & RT_CTX_TIMING)) return RT_OK;
+int timed_begin(rt_context *c, int kind, bool on = true) {
+    if (!(c->flags & RT_CTX_TIMING) || !on) return RT_OK;
     while (c->ev_pool.size() < c->ev_used + 2) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
@@ -154,8 +155,8 @@ int timed_begin(rt_context *c, int kind) {
     return RT_OK;
 }
 
-int timed_end(rt_context *c) {
-    if (!(c->flags & RT_CTX_TIMING)) return RT_OK;
+int timed_end(rt_context *c, bool on = true) {
+    if (!(c->flags & RT_CTX_TIMING) || !on) return RT_OK;
     HIP_TRY(hipEventRecord(c->ev_pool[c->ev_used + 1], c->stream));
     c->ev_used += 2;
     return RT_OK;
@@ -276,6 +277,12 @@ RT_API int rt_context_synchronize(rt_context *c) {
     if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+RT_API int rt_context_set_timed_bounces(rt_context *c, uint32_t bounces) {
+    if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
+    c->timed_bounces = bounces ? bounces : 0xFFFFFFFFu;
     return RT_OK;
 }
 
@@ -567,14 +574,15 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             // bounce `it` consumes queue (it-1)&1 with the per-block counts of row `it`, and produces queue it&1
             // with row it+1; bounce 0 consumes the identity queue.
             rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
-            if (int rc = timed_begin(c, K_EXTEND)) return rc;
+            const bool timed = it < c->timed_bounces;
+            if (int rc = timed_begin(c, K_EXTEND, timed)) return rc;
             rt::launch_extend(c->stream, grid, s->dev, ps.ray_o, ps.ray_d, ps.hit, q, cam->z_near, cam->z_far, true,
                               count ? c->counters.ptr : nullptr);
-            if (int rc = timed_end(c)) return rc;
-            if (int rc = timed_begin(c, K_SHADE)) return rc;
+            if (int rc = timed_end(c, timed)) return rc;
+            if (int rc = timed_begin(c, K_SHADE, timed)) return rc;
             rt::launch_shade(c->stream, grid, s->dev, P, ps, q, c->queue[it & 1].ptr,
                              c->counts.ptr + (size_t)(it + 1) * grid, s->need_uv);
-            if (int rc = timed_end(c)) return rc;
+            if (int rc = timed_end(c, timed)) return rc;
             ++extend_launches;
             ++shade_launches;
         }
@@ -595,13 +603,23 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
         stats->total_ms = ms;
-        uint64_t rays = 0;
+        uint64_t rays = 0, timed_rays = 0;
+        uint32_t timed_launches = 0;
         for (uint32_t bi = 0; bi < n_batches; ++bi) {
             const uint32_t b = std::min(B, total - bi * B);
-            if (st->max_depth > 0) rays += (uint64_t)b * npix; // iteration 0 traces every path
-            for (uint32_t it = 1; it < st->max_depth; ++it) rays += c->host_counts[counts_len * bi + it];
+            for (uint32_t it = 0; it < st->max_depth; ++it) {
+                // bounce 0 traces every path of the batch
+                const uint64_t r = it == 0 ? (uint64_t)b * npix : c->host_counts[counts_len * bi + it];
+                rays += r;
+                if ((c->flags & RT_CTX_TIMING) && it < c->timed_bounces) {
+                    timed_rays += r;
+                    ++timed_launches;
+                }
+            }
         }
         stats->rays_traced = rays;
+        stats->timed_extend_rays = timed_rays;
+        stats->timed_extend_launches = timed_launches;
         stats->paths = (uint64_t)total * npix;
         stats->extend_launches = extend_launches;
         stats->shade_launches = shade_launches;

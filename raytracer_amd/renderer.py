@@ -31,6 +31,9 @@ class Context:
     def set_max_paths(self, n: int) -> None:
         F.check(self.lib, self.lib.rt_context_set_max_paths(self.handle, n))
 
+    def set_timed_bounces(self, n: int) -> None:
+        F.check(self.lib, self.lib.rt_context_set_timed_bounces(self.handle, n))
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.rt_context_destroy(self.handle)
