@@ -43,7 +43,7 @@ def cpu_baseline(desc, cam_settings, threads):
     t0 = time.time()
     _, st = oracle.render(cam, rs, threads=threads, rng_mode=ob.RNG_THREAD)
     t1 = time.time() - t0
-    spp = int(max(1, min(64, 15.0 / max(t1, 1e-3))))
+    spp = int(max(1, min(1024, 15.0 / max(t1, 1e-3))))
     rs = RenderSettings(WIDTH, HEIGHT, 0, MAX_DEPTH, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=SEED)
     t0 = time.time()
     _, st = oracle.render(cam, rs, threads=threads, rng_mode=ob.RNG_THREAD)
