@@ -26,6 +26,7 @@ RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE = 0, 1, 2
 RT_MODE_LINEAR_MEAN, RT_MODE_GAMMA_PER_SAMPLE = 0, 1
 RT_MISS = 0xFFFFFFFF
 RT_CTX_TIMING, RT_CTX_COUNTERS = 1, 2
+RT_PIPELINE_AUTO, RT_PIPELINE_SPLIT, RT_PIPELINE_FUSED, RT_PIPELINE_FUSED_LDS = 0, 1, 2, 3
 
 _f3 = C.c_float * 3
 
@@ -100,7 +101,7 @@ class rt_stats(C.Structure):
                 ("total_ms", C.c_double), ("generate_ms", C.c_double), ("extend_ms", C.c_double),
                 ("shade_ms", C.c_double), ("accumulate_ms", C.c_double),
                 ("timed_extend_rays", C.c_uint64), ("timed_extend_launches", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("pipeline", C.c_uint32), ("bounce_ms", C.c_double)]
 
 
 # numpy dtypes with the same layout as rt_ray / rt_hit (both are 4-byte-aligned plain records).
@@ -118,6 +119,7 @@ EXPORTS = {
     "rt_context_synchronize": (C.c_int, [_vp]),
     "rt_context_set_max_paths": (C.c_int, [_vp, C.c_uint64]),
     "rt_context_set_timed_bounces": (C.c_int, [_vp, C.c_uint32]),
+    "rt_context_set_pipeline": (C.c_int, [_vp, C.c_uint32]),
     "rt_scene_create": (C.c_int, [_vp, C.POINTER(rt_scene_desc), C.POINTER(_vp)]),
     "rt_scene_destroy": (C.c_int, [_vp]),
     "rt_scene_get_info": (C.c_int, [_vp, C.POINTER(rt_scene_info)]),

@@ -65,7 +65,7 @@ template <class T> struct DevBuf {
     }
 };
 
-enum KernelKind { K_GENERATE = 0, K_EXTEND = 1, K_SHADE = 2, K_ACCUMULATE = 3, K_KINDS = 4 };
+enum KernelKind { K_GENERATE = 0, K_EXTEND = 1, K_SHADE = 2, K_ACCUMULATE = 3, K_BOUNCE = 4, K_KINDS = 5 };
 
 } // namespace
 
@@ -77,6 +77,7 @@ struct rt_context {
     uint32_t max_blocks = 2048;
     uint64_t max_paths = 1ull << 24;
     uint32_t timed_bounces = 0xFFFFFFFFu;
+    uint32_t pipeline = RT_PIPELINE_AUTO;
 
     // wavefront workspace
     DevBuf<float4> ray_o, ray_d, hit, beta, radiance;
@@ -164,7 +165,7 @@ int timed_end(rt_context *c, bool on = true) {
 
 int collect_timing(rt_context *c, rt_stats *st) {
     if (!(c->flags & RT_CTX_TIMING)) return RT_OK;
-    double sums[K_KINDS] = {0, 0, 0, 0};
+    double sums[K_KINDS] = {0, 0, 0, 0, 0};
     for (const auto &s : c->spans) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[s.a], c->ev_pool[s.b]));
@@ -174,6 +175,7 @@ int collect_timing(rt_context *c, rt_stats *st) {
     st->extend_ms = sums[K_EXTEND];
     st->shade_ms = sums[K_SHADE];
     st->accumulate_ms = sums[K_ACCUMULATE];
+    st->bounce_ms = sums[K_BOUNCE];
     return RT_OK;
 }
 
@@ -277,6 +279,13 @@ RT_API int rt_context_synchronize(rt_context *c) {
     if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+RT_API int rt_context_set_pipeline(rt_context *c, uint32_t pipeline) {
+    if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
+    if (pipeline > RT_PIPELINE_FUSED_LDS) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown pipeline %u", pipeline);
+    c->pipeline = pipeline;
     return RT_OK;
 }
 
@@ -556,6 +565,16 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     rt::PathState ps{c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, c->beta.ptr, c->radiance.ptr};
     const bool count = stats && (c->flags & RT_CTX_COUNTERS);
     if (count) HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(rt::ExtendCounters), c->stream));
+    // Pipeline choice.  The instrumented extend kernel only exists in the split pipeline.
+    const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
+    uint32_t pipeline = c->pipeline;
+    if (count) pipeline = RT_PIPELINE_SPLIT;
+    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 40u * 1024u ? RT_PIPELINE_FUSED_LDS : RT_PIPELINE_FUSED;
+    if (pipeline == RT_PIPELINE_FUSED_LDS && table_bytes > 64u * 1024u)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
+                         (unsigned long long)table_bytes);
+    const bool fused = pipeline != RT_PIPELINE_SPLIT;
+    const uint32_t lds_bytes = pipeline == RT_PIPELINE_FUSED_LDS ? (uint32_t)table_bytes : 0u;
     c->spans.clear();
     c->ev_used = 0;
     if (stats) HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
@@ -567,25 +586,38 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         const uint32_t n = b * npix;
         P.sample_base = st->sample_begin + s0;
         P.batch_samples = b;
-        if (int rc = timed_begin(c, K_GENERATE)) return rc;
-        rt::launch_generate(c->stream, c->max_blocks, P, ps, n);
-        if (int rc = timed_end(c)) return rc;
-        for (uint32_t it = 0; it < st->max_depth; ++it) {
-            // bounce `it` consumes queue (it-1)&1 with the per-block counts of row `it`, and produces queue it&1
-            // with row it+1; bounce 0 consumes the identity queue.
-            rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
-            const bool timed = it < c->timed_bounces;
-            if (int rc = timed_begin(c, K_EXTEND, timed)) return rc;
-            rt::launch_extend(c->stream, grid, s->dev, ps.ray_o, ps.ray_d, ps.hit, q, cam->z_near, cam->z_far, true,
-                              count ? c->counters.ptr : nullptr);
-            if (int rc = timed_end(c, timed)) return rc;
-            if (int rc = timed_begin(c, K_SHADE, timed)) return rc;
-            rt::launch_shade(c->stream, grid, s->dev, P, ps, q, c->queue[it & 1].ptr,
-                             c->counts.ptr + (size_t)(it + 1) * grid, s->need_uv);
-            if (int rc = timed_end(c, timed)) return rc;
-            ++extend_launches;
-            ++shade_launches;
+        if (fused) {
+            for (uint32_t it = 0; it < st->max_depth; ++it) {
+                rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
+                const bool timed = it < c->timed_bounces;
+                if (int rc = timed_begin(c, K_BOUNCE, timed)) return rc;
+                rt::launch_bounce(c->stream, grid, s->dev, P, ps, q, c->queue[it & 1].ptr,
+                                  c->counts.ptr + (size_t)(it + 1) * grid, it == 0, s->need_uv, lds_bytes);
+                if (int rc = timed_end(c, timed)) return rc;
+                ++extend_launches;
+            }
+        } else {
+            if (int rc = timed_begin(c, K_GENERATE)) return rc;
+            rt::launch_generate(c->stream, c->max_blocks, P, ps, n);
+            if (int rc = timed_end(c)) return rc;
+            for (uint32_t it = 0; it < st->max_depth; ++it) {
+                // bounce `it` consumes queue (it-1)&1 with the per-block counts of row `it`, and produces queue
+                // it&1 with row it+1; bounce 0 consumes the identity queue.
+                rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
+                const bool timed = it < c->timed_bounces;
+                if (int rc = timed_begin(c, K_EXTEND, timed)) return rc;
+                rt::launch_extend(c->stream, grid, s->dev, ps.ray_o, ps.ray_d, ps.hit, q, cam->z_near, cam->z_far, true,
+                                  count ? c->counters.ptr : nullptr);
+                if (int rc = timed_end(c, timed)) return rc;
+                if (int rc = timed_begin(c, K_SHADE, timed)) return rc;
+                rt::launch_shade(c->stream, grid, s->dev, P, ps, q, c->queue[it & 1].ptr,
+                                 c->counts.ptr + (size_t)(it + 1) * grid, s->need_uv);
+                if (int rc = timed_end(c, timed)) return rc;
+                ++extend_launches;
+                ++shade_launches;
+            }
         }
+        if (st->max_depth == 0) HIP_TRY(hipMemsetAsync(ps.radiance, 0, (size_t)n * sizeof(float4), c->stream));
         if (int rc = timed_begin(c, K_ACCUMULATE)) return rc;
         rt::launch_accumulate(c->stream, c->max_blocks, P, ps.radiance, d_accum);
         if (int rc = timed_end(c)) return rc;
@@ -620,6 +652,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         stats->rays_traced = rays;
         stats->timed_extend_rays = timed_rays;
         stats->timed_extend_launches = timed_launches;
+        stats->pipeline = pipeline;
         stats->paths = (uint64_t)total * npix;
         stats->extend_launches = extend_launches;
         stats->shade_launches = shade_launches;

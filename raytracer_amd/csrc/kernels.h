@@ -21,6 +21,13 @@ void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float
 void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv);
 
+// One whole path segment per item: camera ray generation (`first`), closest hit, shading, compaction.
+// `lds_bytes` != 0 stages the node and primitive tables in that many bytes of LDS (2 * 16 * n_nodes +
+// 3 * 16 * n_prims); the caller decides whether they fit.
+void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
+                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool first, bool need_uv,
+                   uint32_t lds_bytes);
+
 // totals[r] = sum of counts[r * n_blocks .. (r + 1) * n_blocks) for r in [0, n_rows).
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals);

@@ -101,15 +101,15 @@ __device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uin
 // BvhNode::hit (src/bvh.rs:295-317) as a stackless pre-order walk.  `best.t` plays the role of the
 // shrinking `hit_range.max`: the reference hands the right sibling max = the left hit's distance, and every
 // later node therefore sees the closest distance found so far in visiting order.
+// `nodes` / `prims` may point at HBM or at a copy of the tables in LDS.
 template <bool COUNT>
-__device__ __forceinline__ Closest traverse(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax,
+__device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ prims,
+                                            uint32_t n_nodes, V3 o, V3 d, float tmin, float tmax,
                                             uint32_t &n_nodes_visited, uint32_t &n_tri, uint32_t &n_sph) {
-    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
-    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
     uint32_t idx = 0;
-    const uint32_t end = sc.n_nodes;
+    const uint32_t end = n_nodes;
     while (idx < end) {
         float4 nlo = nodes[2 * idx];
         float4 nhi = nodes[2 * idx + 1];
@@ -171,10 +171,9 @@ __device__ __forceinline__ void sphere_uv(V3 p, float &u, float &v) {
 // What TriangleRef::hit / Sphere::hit compute after the range test plus HitRecord::new
 // (src/object/triangle_mesh.rs:172-187, src/object/sphere.rs:73-82, src/object/mod.rs:39-62).
 template <bool NEED_UV>
-__device__ __forceinline__ Surface make_surface(const SceneDev &sc, V3 o, V3 d, float t, uint32_t leaf, float u,
-                                                float v) {
+__device__ __forceinline__ Surface make_surface(const SceneDev &sc, const float4 *__restrict__ prims, V3 o, V3 d,
+                                                float t, uint32_t leaf, float u, float v) {
     Surface s;
-    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     uint32_t slot = leaf & ~kSphereBit;
     s.point = o + d * t;
     V3 outward;
@@ -364,34 +363,42 @@ __device__ __forceinline__ bool scatter_leaf(const SceneDev &sc, const MaterialR
 // ------------------------------------------------------------------------------------------------------
 // generate: Camera::get_ray (src/camera.rs:68-93) for every (sample, pixel) of the batch
 // ------------------------------------------------------------------------------------------------------
+// Camera::get_ray (src/camera.rs:68-93) for path `slot` of the batch; returns the draw counter after it.
+__device__ __forceinline__ uint32_t generate_ray(const RenderParams &P, uint32_t slot, V3 &origin, V3 &dir,
+                                                 uint32_t &s_local, uint32_t &pixel) {
+    s_local = slot / P.npix;
+    pixel = slot - s_local * P.npix;
+    uint32_t j = pixel / P.width;
+    uint32_t i = pixel - j * P.width;
+    Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, 0u);
+    uint32_t a, b;
+    rng_next_2u32(rng, a, b);
+    float ox = u32_to_unit(a) - 0.5f;
+    float oy = u32_to_unit(b) - 0.5f;
+    V3 pixel_sample = (ld3(P.pixel_00_loc) + ld3(P.pixel_delta_u) * ((float)i + ox)) +
+                      ld3(P.pixel_delta_v) * ((float)j + oy);
+    if (P.defocus_angle <= 0.0f) {
+        origin = ld3(P.center);
+    } else {
+        float px, py; // gen_unit_disk (src/vec3.rs:74-81)
+        for (;;) {
+            px = rng_random_range(rng, -1.0f, 1.0f);
+            py = rng_random_range(rng, -1.0f, 1.0f);
+            V3 p = V3{px, py, 0.0f};
+            if (length_squared(p) < 1.0f) break;
+        }
+        origin = (ld3(P.center) + ld3(P.defocus_disk_u) * px) + ld3(P.defocus_disk_v) * py;
+    }
+    dir = pixel_sample - origin;
+    return rng.k;
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate(RenderParams P, PathState st, uint32_t n_slots) {
     for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n_slots; slot += gridDim.x * kBlock) {
-        uint32_t s_local = slot / P.npix;
-        uint32_t pixel = slot - s_local * P.npix;
-        uint32_t j = pixel / P.width;
-        uint32_t i = pixel - j * P.width;
-        Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, 0u);
-        uint32_t a, b;
-        rng_next_2u32(rng, a, b);
-        float ox = u32_to_unit(a) - 0.5f;
-        float oy = u32_to_unit(b) - 0.5f;
-        V3 pixel_sample = (ld3(P.pixel_00_loc) + ld3(P.pixel_delta_u) * ((float)i + ox)) +
-                          ld3(P.pixel_delta_v) * ((float)j + oy);
-        V3 origin;
-        if (P.defocus_angle <= 0.0f) {
-            origin = ld3(P.center);
-        } else {
-            float px, py; // gen_unit_disk (src/vec3.rs:74-81)
-            for (;;) {
-                px = rng_random_range(rng, -1.0f, 1.0f);
-                py = rng_random_range(rng, -1.0f, 1.0f);
-                V3 p = V3{px, py, 0.0f};
-                if (length_squared(p) < 1.0f) break;
-            }
-            origin = (ld3(P.center) + ld3(P.defocus_disk_u) * px) + ld3(P.defocus_disk_v) * py;
-        }
-        V3 dir = pixel_sample - origin;
-        st.ray_o[slot] = mk4(origin, u2f(rng.k));
+        V3 origin, dir;
+        uint32_t s_local, pixel;
+        uint32_t k = generate_ray(P, slot, origin, dir, s_local, pixel);
+        st.ray_o[slot] = mk4(origin, u2f(k));
         st.ray_d[slot] = mk4(dir, u2f(s_local << 16));
         st.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         st.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -436,7 +443,9 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
         uint32_t slot = c.ident ? i : q.items[c.seg + i];
         V3 o = xyz(ray_o[slot]);
         V3 d = xyz(ray_d[slot]);
-        Closest best = USE_BVH ? traverse<COUNT>(sc, o, d, tmin, tmax, c_nodes, c_tri, c_sph)
+        Closest best = USE_BVH ? traverse<COUNT>(reinterpret_cast<const float4 *>(sc.nodes),
+                                                 reinterpret_cast<const float4 *>(sc.prims), sc.n_nodes, o, d, tmin, tmax,
+                                                 c_nodes, c_tri, c_sph)
                                : scan_world(sc, o, d, tmin, tmax);
         hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
     }
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
                 uint32_t meta = f2u(d4.w);
                 uint32_t depth = meta & 0xFFFFu;
                 uint32_t s_local = meta >> 16;
-                Surface s = make_surface<NEED_UV>(sc, o, d, h.x, leaf, h.z, h.w);
+                Surface s = make_surface<NEED_UV>(sc, reinterpret_cast<const float4 *>(sc.prims), o, d, h.x, leaf, h.z, h.w);
                 const MaterialRec m = sc.materials[s.material];
                 // src/renderer.rs:48: l += beta * emit.  Non-emitters contribute beta * 0, which is NaN once
                 // beta holds an infinity, exactly as in the reference.
@@ -522,6 +531,104 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
             st.radiance[slot] = mk4(l, 0.0f);
         }
         // Queue compaction: lanes ranked by ballot + popcount, one LDS atomic per wave.
+        unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t total = __popcll(mask);
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(&s_out, total);
+            start = __shfl(start, 0);
+            if (alive) queue_out[c.seg + start + rank] = slot;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts_out[blockIdx.x] = s_out;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// bounce: generate (first bounce only) + extend + shade of one path segment in a single kernel.
+//
+// Compared with the split kernels this keeps the ray and the hit in registers between traversal and shading
+// and drops the per-path radiance from the in-flight state: until a path ends its radiance is, per channel,
+// either +0 or NaN (only emitters add anything else and they end the path, src/material.rs:129-137;
+// `l += beta * 0` turns a channel NaN once beta is not finite, src/renderer.rs:48), so three flag bits next
+// to the draw counter carry it and `radiance[slot]` is written exactly once, when the path ends.
+//   ray_o.w = k (bits 0..23) | NaN flags (bits 24..26);  ray_d.w = depth | sample_in_batch << 16
+// With LDS_SCENE the node and primitive tables are first copied into LDS and traversal reads them there.
+// ------------------------------------------------------------------------------------------------------
+template <bool FIRST, bool LDS_SCENE, bool NEED_UV>
+__global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
+                                                   uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out) {
+    extern __shared__ float4 s_scene[];
+    __shared__ uint32_t s_out;
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
+    if (LDS_SCENE) {
+        const uint32_t n4_nodes = 2u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
+        for (uint32_t i = threadIdx.x; i < n4_nodes; i += kBlock) s_scene[i] = nodes[i];
+        for (uint32_t i = threadIdx.x; i < n4_prims; i += kBlock) s_scene[n4_nodes + i] = prims[i];
+        nodes = s_scene;
+        prims = s_scene + n4_nodes;
+    }
+    if (threadIdx.x == 0) s_out = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    QueueCursor c = queue_begin(q);
+    for (uint32_t off = c.off; off < c.limit; off += c.stride) {
+        const uint32_t i = off + threadIdx.x;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < c.limit) {
+            V3 o, d, beta;
+            uint32_t k, flags, depth, s_local, pixel;
+            if (FIRST) {
+                slot = i;
+                k = generate_ray(P, slot, o, d, s_local, pixel);
+                beta = V3{1.0f, 1.0f, 1.0f};
+                flags = 0u;
+                depth = 0u;
+            } else {
+                slot = q.items[c.seg + i];
+                float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+                o = xyz(o4);
+                d = xyz(d4);
+                beta = xyz(st.beta[slot]);
+                k = f2u(o4.w) & 0xFFFFFFu;
+                flags = f2u(o4.w) >> 24;
+                depth = f2u(d4.w) & 0xFFFFu;
+                s_local = f2u(d4.w) >> 16;
+                pixel = slot - s_local * P.npix;
+            }
+            uint32_t c0 = 0, c1 = 0, c2 = 0;
+            Closest best = traverse<false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+            const float qnan = __builtin_nanf("");
+            V3 l = V3{(flags & 1u) ? qnan : 0.0f, (flags & 2u) ? qnan : 0.0f, (flags & 4u) ? qnan : 0.0f};
+            if (best.slot == kMissSlot) {
+                l = ld3(P.background); // src/renderer.rs:59-63
+            } else {
+                Surface s = make_surface<NEED_UV>(sc, prims, o, d, best.t, best.slot, best.u, best.v);
+                const MaterialRec m = sc.materials[s.material];
+                V3 emit = V3{0.0f, 0.0f, 0.0f};
+                if (m.kind == 3u) emit = material_color(sc, m, s) * m.param;
+                l = l + beta * emit; // src/renderer.rs:48
+                Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, k);
+                Scatter sr;
+                if (scatter_leaf(sc, m, d, s, rng, sr)) {
+                    V3 f = (sr.attenuation * fabsf(dot(sr.direction, s.normal))) / sr.pdf; // src/renderer.rs:51-54
+                    beta = beta * f;
+                    depth += 1u;
+                    alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
+                    if (alive) {
+                        // a scattering material emits nothing, so l is still +0 or NaN per channel here
+                        flags = (l.x != l.x ? 1u : 0u) | (l.y != l.y ? 2u : 0u) | (l.z != l.z ? 4u : 0u);
+                        st.ray_o[slot] = mk4(s.point, u2f((rng.k & 0xFFFFFFu) | (flags << 24)));
+                        st.ray_d[slot] = mk4(sr.direction, u2f((s_local << 16) | depth));
+                        st.beta[slot] = mk4(beta, 0.0f);
+                    }
+                }
+            }
+            if (!alive) st.radiance[slot] = mk4(l, 0.0f);
+        }
         unsigned long long mask = __ballot(alive);
         if (mask) {
             uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
@@ -598,7 +705,8 @@ __global__ __launch_bounds__(kBlock) void k_finalize_hits(SceneDev sc, const flo
             o[0] = 0u; o[1] = 0xFFFFFFFFu; o[2] = 0u; o[3] = 0u; o[4] = 0u; o[5] = 0u; o[6] = 0u; o[7] = 0u;
             continue;
         }
-        Surface s = make_surface<false>(sc, xyz(ray_o[i]), xyz(ray_d[i]), h.x, leaf, h.z, h.w);
+        Surface s = make_surface<false>(sc, reinterpret_cast<const float4 *>(sc.prims), xyz(ray_o[i]), xyz(ray_d[i]), h.x, leaf,
+                                        h.z, h.w);
         o[0] = f2u(h.x);
         o[1] = s.prim_id;
         o[2] = f2u(h.z);
@@ -641,6 +749,33 @@ void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
         hipLaunchKernelGGL((k_shade<true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
     else
         hipLaunchKernelGGL((k_shade<false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+}
+
+template <bool FIRST>
+static void launch_bounce_t(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
+                            const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv,
+                            uint32_t lds_bytes) {
+    dim3 g(grid), b(kBlock);
+    if (lds_bytes) {
+        if (need_uv)
+            hipLaunchKernelGGL((k_bounce<FIRST, true, true>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out);
+        else
+            hipLaunchKernelGGL((k_bounce<FIRST, true, false>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out);
+    } else {
+        if (need_uv)
+            hipLaunchKernelGGL((k_bounce<FIRST, false, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+        else
+            hipLaunchKernelGGL((k_bounce<FIRST, false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+    }
+}
+
+void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
+                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool first, bool need_uv,
+                   uint32_t lds_bytes) {
+    if (first)
+        launch_bounce_t<true>(s, grid, sc, P, st, q, queue_out, counts_out, need_uv, lds_bytes);
+    else
+        launch_bounce_t<false>(s, grid, sc, P, st, q, queue_out, counts_out, need_uv, lds_bytes);
 }
 
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, uint32_t n_blocks, uint32_t n_rows,

@@ -31,6 +31,9 @@ class Context:
     def set_max_paths(self, n: int) -> None:
         F.check(self.lib, self.lib.rt_context_set_max_paths(self.handle, n))
 
+    def set_pipeline(self, pipeline: int) -> None:
+        F.check(self.lib, self.lib.rt_context_set_pipeline(self.handle, pipeline))
+
     def set_timed_bounces(self, n: int) -> None:
         F.check(self.lib, self.lib.rt_context_set_timed_bounces(self.handle, n))
 

@@ -220,6 +220,35 @@ def test_rtiow_spheres_with_defocus_and_background(gpu_ctx):
     assert gst.rays_traced / gst.paths > 1.5
 
 
+@pytest.mark.parametrize("pipeline", [F.RT_PIPELINE_SPLIT, F.RT_PIPELINE_FUSED, F.RT_PIPELINE_FUSED_LDS])
+def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
+    """Split kernels (generate / extend / shade), the fused per-bounce kernel, and the fused kernel with the
+    scene tables in LDS must all give the oracle's sums bit for bit."""
+    ctx = Context(0, flags=F.RT_CTX_TIMING)
+    ctx.set_pipeline(pipeline)
+    cases = [(cornell_with(cornell), None, RenderSettings(120, 90, 0, 50, 6, mode=F.RT_MODE_LINEAR_MEAN, seed=3,
+                                                          background_color=(0.2, 0.1, 0.3))),
+             (cornell, None, RenderSettings(150, 100, 0, 50, 9, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=4)),
+             (cornell, None, RenderSettings(31, 17, 0, 1, 3, mode=F.RT_MODE_LINEAR_MEAN, seed=5)),
+             (cornell, None, RenderSettings(9, 9, 0, 0, 2, mode=F.RT_MODE_LINEAR_MEAN, seed=5))]
+    sph, sph_cam = rtiow_final_scene()
+    cases.append((sph, sph_cam, RenderSettings(160, 90, 0, 50, 4, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=6,
+                                               background_color=(0.7, 0.8, 1.0))))
+    if pipeline != F.RT_PIPELINE_FUSED_LDS:
+        lit, lit_cam = lit_teapot(teapot)
+        cases.append((lit, lit_cam, RenderSettings(120, 80, 0, 50, 3, mode=F.RT_MODE_LINEAR_MEAN, seed=7)))
+    for desc, cs, rs in cases:
+        gpu, cpu, gst, cst = render_pair(ctx, desc, cs or desc.camera(0), rs)
+        assert_images_equal(gpu, cpu)
+        assert gst.rays_traced == cst.rays_traced
+        assert gst.pipeline == pipeline
+    if pipeline == F.RT_PIPELINE_FUSED_LDS:  # tables too large for LDS -> a clear error, not a fault
+        with pytest.raises(F.RtError) as e:
+            render_pair(ctx, teapot, teapot.camera(0), RenderSettings(16, 16, 0, 4, 1))
+        assert e.value.code == F.RT_ERR_INVALID_ARGUMENT and "LDS" in e.value.message
+    ctx.close()
+
+
 def test_teapot_default_camera_is_black_and_lit_variant_matches(gpu_ctx, teapot):
     """Config 2 as the reference would run it: no camera, no light, background 0 -> identically zero image."""
     rs = RenderSettings(160, 90, 0, 50, 2, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=1)

@@ -19,8 +19,12 @@ def main():
     h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
     spp = int(sys.argv[4]) if len(sys.argv) > 4 else 16
     flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    pipeline = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    max_paths = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     desc = load_from_gltf(os.path.join(ROOT, "assets", f"{name}.gltf"))
     ctx = Context(0, flags=flags)
+    ctx.set_pipeline(pipeline)
+    ctx.set_max_paths(max_paths)
     t0 = time.time()
     scene = Scene(ctx, desc)
     i = scene.info()
@@ -35,7 +39,7 @@ def main():
         st = r.last_stats
         print(f"rep {rep}: wall {dt*1e3:.1f} ms, gpu {st.total_ms:.1f} ms, rays {st.rays_traced} paths {st.paths} "
               f"rays/path {st.rays_traced/st.paths:.3f} -> {st.rays_traced/st.total_ms/1e3:.1f} Mrays/s; "
-              f"gen {st.generate_ms:.2f} ext {st.extend_ms:.2f} shade {st.shade_ms:.2f} acc {st.accumulate_ms:.2f} ms; "
+              f"pipe {st.pipeline} bounce {st.bounce_ms:.2f} gen {st.generate_ms:.2f} ext {st.extend_ms:.2f} shade {st.shade_ms:.2f} acc {st.accumulate_ms:.2f} ms; "
               f"nodes/ray {st.node_visits/max(1,st.rays_traced):.2f} tri/ray {st.triangle_tests/max(1,st.rays_traced):.2f}")
     img /= spp
     fin = np.isfinite(img)
