@@ -231,7 +231,10 @@ typedef struct rt_stats {
     uint64_t timed_extend_rays;     /* rays processed by the extend launches that extend_ms covers */
     uint32_t timed_extend_launches; /* number of those launches */
     uint32_t pipeline;              /* RT_PIPELINE_* the call actually used */
-    double bounce_ms;               /* fused pipeline: time of the timed bounce launches (timed_extend_* count them) */
+    double bounce_ms;               /* time of the timed launches of the fused bounce kernel */
+    uint64_t timed_bounce_rays;     /* rays processed by the bounce launches that bounce_ms covers */
+    uint32_t timed_bounce_launches;
+    uint32_t bounce_launches;
 } rt_stats;
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -262,11 +265,21 @@ int rt_context_synchronize(rt_context *ctx);
 /* Upper bound on concurrently traced paths (slots of wavefront state).  0 restores the default. */
 int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
 /* Which kernels render a batch.  All pipelines produce bit-identical sums.
- *   SPLIT      generate, then per bounce extend + shade (hit records and radiance travel through HBM)
- *   FUSED      per bounce one kernel: (generate +) extend + shade, ray and hit stay in registers
- *   FUSED_LDS  FUSED with the BVH and primitive tables staged in LDS (only for scenes whose tables fit)
- *   AUTO       FUSED_LDS when the tables fit in 40 KB of LDS, else FUSED */
-enum { RT_PIPELINE_AUTO = 0, RT_PIPELINE_SPLIT = 1, RT_PIPELINE_FUSED = 2, RT_PIPELINE_FUSED_LDS = 3 };
+ *   SPLIT   generate, then per bounce extend + shade (the hit record travels through HBM)
+ *   FUSED   per bounce one kernel: (generate +) extend + shade, ray and hit stay in registers
+ *   HYBRID  bounce 0 (coherent camera rays) by the fused kernel, later bounces (incoherent rays, very uneven
+ *           traversal lengths) by extend with per-lane ray refill, then shade
+ *   *_LDS   the same with the BVH and primitive tables staged in LDS (only for scenes whose tables fit)
+ *   AUTO    FUSED_LDS when the tables fit in 40 KB of LDS, else FUSED (the fastest measured on every scene) */
+enum {
+    RT_PIPELINE_AUTO = 0,
+    RT_PIPELINE_SPLIT = 1,
+    RT_PIPELINE_FUSED = 2,
+    RT_PIPELINE_FUSED_LDS = 3,
+    RT_PIPELINE_HYBRID = 4,
+    RT_PIPELINE_HYBRID_LDS = 5,
+    RT_PIPELINE_SPLIT_LDS = 6
+};
 int rt_context_set_pipeline(rt_context *ctx, uint32_t pipeline);
 /* With RT_CTX_TIMING, bracket only the launches of the first `bounces` bounces of every batch with events
  * (the later bounces of a batch carry a vanishing share of the rays but most of the launches).  0 = all. */

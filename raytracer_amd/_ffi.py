@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt_mi355x.so")
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "csrc", "librt_mi355x.so")
 
 RT_OK = 0
 RT_ERR_INVALID_ARGUMENT = -1
@@ -26,7 +26,8 @@ RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE = 0, 1, 2
 RT_MODE_LINEAR_MEAN, RT_MODE_GAMMA_PER_SAMPLE = 0, 1
 RT_MISS = 0xFFFFFFFF
 RT_CTX_TIMING, RT_CTX_COUNTERS = 1, 2
-RT_PIPELINE_AUTO, RT_PIPELINE_SPLIT, RT_PIPELINE_FUSED, RT_PIPELINE_FUSED_LDS = 0, 1, 2, 3
+(RT_PIPELINE_AUTO, RT_PIPELINE_SPLIT, RT_PIPELINE_FUSED, RT_PIPELINE_FUSED_LDS, RT_PIPELINE_HYBRID,
+ RT_PIPELINE_HYBRID_LDS, RT_PIPELINE_SPLIT_LDS) = range(7)
 
 _f3 = C.c_float * 3
 
@@ -101,7 +102,8 @@ class rt_stats(C.Structure):
                 ("total_ms", C.c_double), ("generate_ms", C.c_double), ("extend_ms", C.c_double),
                 ("shade_ms", C.c_double), ("accumulate_ms", C.c_double),
                 ("timed_extend_rays", C.c_uint64), ("timed_extend_launches", C.c_uint32),
-                ("pipeline", C.c_uint32), ("bounce_ms", C.c_double)]
+                ("pipeline", C.c_uint32), ("bounce_ms", C.c_double), ("timed_bounce_rays", C.c_uint64),
+                ("timed_bounce_launches", C.c_uint32), ("bounce_launches", C.c_uint32)]
 
 
 # numpy dtypes with the same layout as rt_ray / rt_hit (both are 4-byte-aligned plain records).

@@ -284,7 +284,7 @@ RT_API int rt_context_synchronize(rt_context *c) {
 
 RT_API int rt_context_set_pipeline(rt_context *c, uint32_t pipeline) {
     if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
-    if (pipeline > RT_PIPELINE_FUSED_LDS) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown pipeline %u", pipeline);
+    if (pipeline > RT_PIPELINE_SPLIT_LDS) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown pipeline %u", pipeline);
     c->pipeline = pipeline;
     return RT_OK;
 }
@@ -466,8 +466,12 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     if (int rc = timed_begin(c, K_EXTEND)) return rc;
     const rt::QueueView all{nullptr, nullptr, 0u, (uint32_t)n};
     const uint32_t grid = (uint32_t)std::min<uint64_t>(c->max_blocks, (n + 255) / 256);
+    const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
+    const bool want_lds = c->pipeline == RT_PIPELINE_AUTO || c->pipeline == RT_PIPELINE_FUSED_LDS ||
+                          c->pipeline == RT_PIPELINE_HYBRID_LDS || c->pipeline == RT_PIPELINE_SPLIT_LDS;
+    const uint32_t lds_bytes = want_lds && table_bytes <= 40u * 1024u ? (uint32_t)table_bytes : 0u;
     rt::launch_extend(c->stream, grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, all, t_min, t_max, use_bvh != 0,
-                      count ? c->counters.ptr : nullptr);
+                      count ? c->counters.ptr : nullptr, lds_bytes);
     if (int rc = timed_end(c)) return rc;
     rt::launch_finalize_hits(c->stream, c->max_blocks, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, d_out);
     HIP_TRY(hipGetLastError());
@@ -565,20 +569,22 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     rt::PathState ps{c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, c->beta.ptr, c->radiance.ptr};
     const bool count = stats && (c->flags & RT_CTX_COUNTERS);
     if (count) HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(rt::ExtendCounters), c->stream));
-    // Pipeline choice.  The instrumented extend kernel only exists in the split pipeline.
+    // Pipeline choice.  The instrumented extend kernel needs a pipeline that runs extend for every bounce.
     const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
     uint32_t pipeline = c->pipeline;
-    if (count) pipeline = RT_PIPELINE_SPLIT;
     if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 40u * 1024u ? RT_PIPELINE_FUSED_LDS : RT_PIPELINE_FUSED;
-    if (pipeline == RT_PIPELINE_FUSED_LDS && table_bytes > 64u * 1024u)
+    const bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS;
+    if (count) pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
+    if (lds && table_bytes > 64u * 1024u)
         return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
                          (unsigned long long)table_bytes);
-    const bool fused = pipeline != RT_PIPELINE_SPLIT;
-    const uint32_t lds_bytes = pipeline == RT_PIPELINE_FUSED_LDS ? (uint32_t)table_bytes : 0u;
+    const bool fused_all = pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
+    const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
+    const uint32_t lds_bytes = lds ? (uint32_t)table_bytes : 0u;
     c->spans.clear();
     c->ev_used = 0;
     if (stats) HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
-    uint32_t extend_launches = 0, shade_launches = 0;
+    uint32_t extend_launches = 0, shade_launches = 0, bounce_launches = 0;
 
     for (uint32_t bi = 0; bi < n_batches; ++bi) {
         const uint32_t s0 = bi * B;
@@ -586,32 +592,30 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         const uint32_t n = b * npix;
         P.sample_base = st->sample_begin + s0;
         P.batch_samples = b;
-        if (fused) {
-            for (uint32_t it = 0; it < st->max_depth; ++it) {
-                rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
-                const bool timed = it < c->timed_bounces;
-                if (int rc = timed_begin(c, K_BOUNCE, timed)) return rc;
-                rt::launch_bounce(c->stream, grid, s->dev, P, ps, q, c->queue[it & 1].ptr,
-                                  c->counts.ptr + (size_t)(it + 1) * grid, it == 0, s->need_uv, lds_bytes);
-                if (int rc = timed_end(c, timed)) return rc;
-                ++extend_launches;
-            }
-        } else {
+        if (!fused_first) {
             if (int rc = timed_begin(c, K_GENERATE)) return rc;
             rt::launch_generate(c->stream, c->max_blocks, P, ps, n);
             if (int rc = timed_end(c)) return rc;
-            for (uint32_t it = 0; it < st->max_depth; ++it) {
-                // bounce `it` consumes queue (it-1)&1 with the per-block counts of row `it`, and produces queue
-                // it&1 with row it+1; bounce 0 consumes the identity queue.
-                rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
-                const bool timed = it < c->timed_bounces;
+        }
+        for (uint32_t it = 0; it < st->max_depth; ++it) {
+            // bounce `it` consumes queue (it-1)&1 with the per-block counts of row `it`, and produces queue it&1
+            // with row it+1; bounce 0 consumes the identity queue.
+            rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
+            uint32_t *q_out = c->queue[it & 1].ptr;
+            uint32_t *counts_out = c->counts.ptr + (size_t)(it + 1) * grid;
+            const bool timed = it < c->timed_bounces;
+            if (fused_all || (fused_first && it == 0)) {
+                if (int rc = timed_begin(c, K_BOUNCE, timed)) return rc;
+                rt::launch_bounce(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, it == 0, s->need_uv, lds_bytes);
+                if (int rc = timed_end(c, timed)) return rc;
+                ++bounce_launches;
+            } else {
                 if (int rc = timed_begin(c, K_EXTEND, timed)) return rc;
                 rt::launch_extend(c->stream, grid, s->dev, ps.ray_o, ps.ray_d, ps.hit, q, cam->z_near, cam->z_far, true,
-                                  count ? c->counters.ptr : nullptr);
+                                  count ? c->counters.ptr : nullptr, lds_bytes);
                 if (int rc = timed_end(c, timed)) return rc;
                 if (int rc = timed_begin(c, K_SHADE, timed)) return rc;
-                rt::launch_shade(c->stream, grid, s->dev, P, ps, q, c->queue[it & 1].ptr,
-                                 c->counts.ptr + (size_t)(it + 1) * grid, s->need_uv);
+                rt::launch_shade(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, s->need_uv);
                 if (int rc = timed_end(c, timed)) return rc;
                 ++extend_launches;
                 ++shade_launches;
@@ -635,8 +639,8 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
         stats->total_ms = ms;
-        uint64_t rays = 0, timed_rays = 0;
-        uint32_t timed_launches = 0;
+        uint64_t rays = 0, timed_extend_rays = 0, timed_bounce_rays = 0;
+        uint32_t timed_extend = 0, timed_bounce = 0;
         for (uint32_t bi = 0; bi < n_batches; ++bi) {
             const uint32_t b = std::min(B, total - bi * B);
             for (uint32_t it = 0; it < st->max_depth; ++it) {
@@ -644,14 +648,22 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
                 const uint64_t r = it == 0 ? (uint64_t)b * npix : c->host_counts[counts_len * bi + it];
                 rays += r;
                 if ((c->flags & RT_CTX_TIMING) && it < c->timed_bounces) {
-                    timed_rays += r;
-                    ++timed_launches;
+                    if (fused_all || (fused_first && it == 0)) {
+                        timed_bounce_rays += r;
+                        ++timed_bounce;
+                    } else {
+                        timed_extend_rays += r;
+                        ++timed_extend;
+                    }
                 }
             }
         }
         stats->rays_traced = rays;
-        stats->timed_extend_rays = timed_rays;
-        stats->timed_extend_launches = timed_launches;
+        stats->timed_extend_rays = timed_extend_rays;
+        stats->timed_extend_launches = timed_extend;
+        stats->timed_bounce_rays = timed_bounce_rays;
+        stats->timed_bounce_launches = timed_bounce;
+        stats->bounce_launches = bounce_launches;
         stats->pipeline = pipeline;
         stats->paths = (uint64_t)total * npix;
         stats->extend_launches = extend_launches;

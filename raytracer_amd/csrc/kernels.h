@@ -13,8 +13,10 @@ namespace rt {
 
 void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const PathState &st, uint32_t n_slots);
 
+// `lds_bytes` != 0 stages the node and primitive tables in LDS (see launch_bounce).
 void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
-                   float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters);
+                   float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters,
+                   uint32_t lds_bytes);
 
 // Shades the items of `q`; block b appends its surviving slots at queue_out[b * q.cap ...] and stores their
 // number in counts_out[b].

@@ -393,15 +393,22 @@ __device__ __forceinline__ uint32_t generate_ray(const RenderParams &P, uint32_t
     return rng.k;
 }
 
+// Path state while a path is in flight (slot = sample_in_batch * npix + pixel):
+//   ray_o = origin.xyz    | k (bits 0..23: index of the next random draw) | NaN flags (bits 24..26)
+//   ray_d = direction.xyz | depth (bits 0..15) | sample_in_batch (bits 16..31)
+//   beta  = throughput.xyz
+// The radiance is not part of it: until a path ends its radiance is, per channel, either +0 or NaN (only
+// emitters add anything else and they end the path, src/material.rs:129-137; `l += beta * 0` turns a channel
+// NaN once beta is not finite, src/renderer.rs:48), so three flag bits carry it and radiance[slot] is written
+// exactly once, when the path ends.
 __global__ __launch_bounds__(kBlock) void k_generate(RenderParams P, PathState st, uint32_t n_slots) {
     for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n_slots; slot += gridDim.x * kBlock) {
         V3 origin, dir;
         uint32_t s_local, pixel;
         uint32_t k = generate_ray(P, slot, origin, dir, s_local, pixel);
-        st.ray_o[slot] = mk4(origin, u2f(k));
+        st.ray_o[slot] = mk4(origin, u2f(k & 0xFFFFFFu));
         st.ray_d[slot] = mk4(dir, u2f(s_local << 16));
         st.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        st.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -428,37 +435,125 @@ __device__ __forceinline__ QueueCursor queue_begin(const QueueView &q) {
     return c;
 }
 
+// Copies the node and primitive tables into LDS (dynamic shared memory) and repoints the table pointers.
+__device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *lds, const float4 *&nodes,
+                                                   const float4 *&prims) {
+    const uint32_t n4_nodes = 2u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
+    for (uint32_t i = threadIdx.x; i < n4_nodes; i += kBlock) lds[i] = nodes[i];
+    for (uint32_t i = threadIdx.x; i < n4_prims; i += kBlock) lds[n4_nodes + i] = prims[i];
+    nodes = lds;
+    prims = lds + n4_nodes;
+}
+
 // ------------------------------------------------------------------------------------------------------
-// extend: closest hit of every queued ray
+// extend: closest hit of every queued ray.
+//
+// Traversal lengths are very uneven (Cornell: 17 box tests per ray on average, but some ray in almost every
+// wave of incoherent rays walks 60+ of the 71 nodes), so a wave that takes 64 rays and walks until the
+// slowest is done keeps a quarter of its lanes busy.  Here every lane owns a slot of a small state machine
+// instead: when kRefillLanes lanes of a wave have finished their ray, they claim the next unclaimed items of
+// the block's queue segment (one LDS atomic per refill), load those rays and join the walk again.
 // ------------------------------------------------------------------------------------------------------
-template <bool COUNT, bool USE_BVH>
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 16
+#endif
+
+template <bool COUNT, bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__restrict__ ray_o,
                                                    const float4 *__restrict__ ray_d, float4 *__restrict__ hits,
                                                    QueueView q, float tmin, float tmax, ExtendCounters *counters) {
+    extern __shared__ float4 s_scene[];
+    __shared__ uint32_t s_next;
+    __shared__ unsigned int s_cnt[3];
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
+    if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
+    if (threadIdx.x == 0) s_next = 0u;
+    if (COUNT && threadIdx.x < 3) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+
+    // the block's pool of items: its queue segment, or its round-robin share of the identity queue's chunks
+    const bool ident = q.items == nullptr;
+    const uint32_t seg = blockIdx.x * q.cap;
+    uint32_t pool;
+    if (ident) {
+        const uint32_t chunks = (q.n + kBlock - 1) / kBlock;
+        pool = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
+    } else {
+        pool = q.counts[blockIdx.x];
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t end = sc.n_nodes;
     uint32_t c_nodes = 0, c_tri = 0, c_sph = 0;
-    QueueCursor c = queue_begin(q);
-    for (uint32_t off = c.off; off < c.limit; off += c.stride) {
-        const uint32_t i = off + threadIdx.x;
-        if (i >= c.limit) break;
-        uint32_t slot = c.ident ? i : q.items[c.seg + i];
-        V3 o = xyz(ray_o[slot]);
-        V3 d = xyz(ray_d[slot]);
-        Closest best = USE_BVH ? traverse<COUNT>(reinterpret_cast<const float4 *>(sc.nodes),
-                                                 reinterpret_cast<const float4 *>(sc.prims), sc.n_nodes, o, d, tmin, tmax,
-                                                 c_nodes, c_tri, c_sph)
-                               : scan_world(sc, o, d, tmin, tmax);
-        hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
+
+    bool have = false, exhausted = false;
+    uint32_t slot = 0, idx = 0;
+    V3 o{}, d{}, inv{};
+    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(!have);
+        const uint32_t n_idle = __popcll(idle_mask);
+        if (!exhausted && (n_idle >= RT_REFILL_LANES)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, n_idle);
+            base = __shfl(base, 0);
+            if (base + n_idle >= pool) exhausted = true;
+            if (!have) {
+                const uint32_t item = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (item < pool) {
+                    bool ok = true;
+                    if (ident) {
+                        slot = ((item / kBlock) * gridDim.x + blockIdx.x) * kBlock + (item % kBlock);
+                        ok = slot < q.n;
+                    } else {
+                        slot = q.items[seg + item];
+                    }
+                    if (ok) {
+                        o = xyz(ray_o[slot]);
+                        d = xyz(ray_d[slot]);
+                        inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+                        best = Closest{tmax, kMissSlot, 0.0f, 0.0f};
+                        idx = 0;
+                        have = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (have) {
+            // one step of BvhNode::hit's pre-order walk (see traverse())
+            float4 nlo = nodes[2 * idx];
+            float4 nhi = nodes[2 * idx + 1];
+            if (COUNT) ++c_nodes;
+            bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+            uint32_t leaf = f2u(nhi.w);
+            if (hit && leaf != kInterior) {
+                uint32_t ps = leaf & ~kSphereBit;
+                if (leaf & kSphereBit) {
+                    if (COUNT) ++c_sph;
+                    sphere_test(prims + 3 * (size_t)ps, ps, o, d, tmin, best);
+                } else {
+                    if (COUNT) ++c_tri;
+                    tri_test(prims + 3 * (size_t)ps, ps, o, d, tmin, best);
+                }
+            }
+            idx = hit ? idx + 1 : f2u(nlo.w);
+            if (idx >= end) {
+                hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
+                have = false;
+            }
+        }
     }
     if (COUNT) { // one atomic per block and counter, skipped when the block saw no work
-        __shared__ unsigned int s_cnt[3];
-        if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0u;
-        __syncthreads();
         for (int sh = 32; sh > 0; sh >>= 1) {
             c_nodes += __shfl_down(c_nodes, sh);
             c_tri += __shfl_down(c_tri, sh);
             c_sph += __shfl_down(c_sph, sh);
         }
-        if ((threadIdx.x & 63u) == 0u) {
+        if (lane == 0u) {
             if (c_nodes) atomicAdd(&s_cnt[0], c_nodes);
             if (c_tri) atomicAdd(&s_cnt[1], c_tri);
             if (c_sph) atomicAdd(&s_cnt[2], c_sph);
@@ -472,9 +567,79 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
     }
 }
 
+// World::hit for every queued ray (tests only; no BVH).
+__global__ __launch_bounds__(kBlock) void k_extend_world(SceneDev sc, const float4 *__restrict__ ray_o,
+                                                         const float4 *__restrict__ ray_d, float4 *__restrict__ hits,
+                                                         QueueView q, float tmin, float tmax) {
+    QueueCursor c = queue_begin(q);
+    for (uint32_t off = c.off; off < c.limit; off += c.stride) {
+        const uint32_t i = off + threadIdx.x;
+        if (i >= c.limit) break;
+        uint32_t slot = c.ident ? i : q.items[c.seg + i];
+        Closest best = scan_world(sc, xyz(ray_o[slot]), xyz(ray_d[slot]), tmin, tmax);
+        hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
-// shade: the body of Renderer::ray_color's loop after `world.hit` (src/renderer.rs:46-66)
+// shading: the body of Renderer::ray_color's loop after `world.hit` (src/renderer.rs:46-66) for one path.
+// Writes the path's next state (and returns true) or its final radiance (and returns false).
 // ------------------------------------------------------------------------------------------------------
+template <bool NEED_UV>
+__device__ __forceinline__ bool shade_path(const SceneDev &sc, const float4 *__restrict__ prims, const RenderParams &P,
+                                           const PathState &st, uint32_t slot, V3 o, V3 d, V3 beta, uint32_t k,
+                                           uint32_t flags, uint32_t depth, uint32_t s_local, uint32_t pixel,
+                                           const Closest &best) {
+    bool alive = false;
+    const float qnan = __builtin_nanf("");
+    V3 l = V3{(flags & 1u) ? qnan : 0.0f, (flags & 2u) ? qnan : 0.0f, (flags & 4u) ? qnan : 0.0f};
+    if (best.slot == kMissSlot) {
+        l = ld3(P.background); // src/renderer.rs:59-63: the background REPLACES the radiance gathered so far
+    } else {
+        Surface s = make_surface<NEED_UV>(sc, prims, o, d, best.t, best.slot, best.u, best.v);
+        const MaterialRec m = sc.materials[s.material];
+        // src/renderer.rs:48: l += beta * emit.  Non-emitters contribute beta * 0, which is NaN once beta holds
+        // an infinity, exactly as in the reference.
+        V3 emit = V3{0.0f, 0.0f, 0.0f};
+        if (m.kind == 3u) emit = material_color(sc, m, s) * m.param;
+        l = l + beta * emit;
+        Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, k);
+        Scatter sr;
+        if (scatter_leaf(sc, m, d, s, rng, sr)) {
+            V3 f = (sr.attenuation * fabsf(dot(sr.direction, s.normal))) / sr.pdf; // src/renderer.rs:51-54
+            beta = beta * f;
+            depth += 1u;
+            // src/renderer.rs:39-41: `while beta != 0` then `depth >= max_depth`
+            alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
+            if (alive) {
+                // a scattering material emits nothing, so l is still +0 or NaN per channel here
+                flags = (l.x != l.x ? 1u : 0u) | (l.y != l.y ? 2u : 0u) | (l.z != l.z ? 4u : 0u);
+                st.ray_o[slot] = mk4(s.point, u2f((rng.k & 0xFFFFFFu) | (flags << 24)));
+                st.ray_d[slot] = mk4(sr.direction, u2f((s_local << 16) | depth));
+                st.beta[slot] = mk4(beta, 0.0f);
+            }
+        }
+    }
+    if (!alive) st.radiance[slot] = mk4(l, 0.0f);
+    return alive;
+}
+
+// Appends the surviving lanes' slots to the block's output segment: ranks from ballot + popcount, one LDS
+// atomic per wave.  Must be reached by all 64 lanes of the wave.
+__device__ __forceinline__ void compact_survivors(bool alive, uint32_t slot, uint32_t lane, uint32_t *s_out,
+                                                  uint32_t *__restrict__ queue_out, uint32_t seg) {
+    unsigned long long mask = __ballot(alive);
+    if (mask) {
+        uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+        uint32_t total = __popcll(mask);
+        uint32_t start = 0;
+        if (lane == 0) start = atomicAdd(s_out, total);
+        start = __shfl(start, 0);
+        if (alive) queue_out[seg + start + rank] = slot;
+    }
+}
+
+// shade: every queued path whose hit record extend has written.
 template <bool NEED_UV>
 __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, PathState st, QueueView q,
                                                   uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out) {
@@ -482,8 +647,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
     if (threadIdx.x == 0) s_out = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
+    const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     QueueCursor c = queue_begin(q);
-    // Whole waves iterate together so that the ballot below always sees all 64 lanes.
+    // Whole waves iterate together so that the ballot in compact_survivors always sees all 64 lanes.
     for (uint32_t off = c.off; off < c.limit; off += c.stride) {
         const uint32_t i = off + threadIdx.x;
         bool alive = false;
@@ -493,68 +659,22 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
             float4 h = st.hit[slot];
             float4 o4 = st.ray_o[slot];
             float4 d4 = st.ray_d[slot];
-            uint32_t leaf = f2u(h.y);
-            V3 l = xyz(st.radiance[slot]);
-            if (leaf == kMissSlot) {
-                // src/renderer.rs:59-63: the background REPLACES the radiance gathered so far.
-                l = ld3(P.background);
-            } else {
-                V3 o = xyz(o4), d = xyz(d4);
-                V3 beta = xyz(st.beta[slot]);
-                uint32_t meta = f2u(d4.w);
-                uint32_t depth = meta & 0xFFFFu;
-                uint32_t s_local = meta >> 16;
-                Surface s = make_surface<NEED_UV>(sc, reinterpret_cast<const float4 *>(sc.prims), o, d, h.x, leaf, h.z, h.w);
-                const MaterialRec m = sc.materials[s.material];
-                // src/renderer.rs:48: l += beta * emit.  Non-emitters contribute beta * 0, which is NaN once
-                // beta holds an infinity, exactly as in the reference.
-                V3 emit = V3{0.0f, 0.0f, 0.0f};
-                if (m.kind == 3u) emit = material_color(sc, m, s) * m.param;
-                l = l + beta * emit;
-                uint32_t pixel = slot - s_local * P.npix;
-                Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, f2u(o4.w));
-                Scatter sr;
-                if (scatter_leaf(sc, m, d, s, rng, sr)) {
-                    // src/renderer.rs:51-54
-                    V3 f = (sr.attenuation * fabsf(dot(sr.direction, s.normal))) / sr.pdf;
-                    beta = beta * f;
-                    depth += 1u;
-                    // src/renderer.rs:39-41: `while beta != 0` then `depth >= max_depth`
-                    alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
-                    if (alive) {
-                        st.ray_o[slot] = mk4(s.point, u2f(rng.k));
-                        st.ray_d[slot] = mk4(sr.direction, u2f((s_local << 16) | depth));
-                        st.beta[slot] = mk4(beta, 0.0f);
-                    }
-                }
-            }
-            st.radiance[slot] = mk4(l, 0.0f);
+            float4 b4 = st.beta[slot];
+            Closest best{h.x, f2u(h.y), h.z, h.w};
+            const uint32_t s_local = f2u(d4.w) >> 16;
+            alive = shade_path<NEED_UV>(sc, prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
+                                        f2u(o4.w) >> 24, f2u(d4.w) & 0xFFFFu, s_local, slot - s_local * P.npix, best);
         }
-        // Queue compaction: lanes ranked by ballot + popcount, one LDS atomic per wave.
-        unsigned long long mask = __ballot(alive);
-        if (mask) {
-            uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-            uint32_t total = __popcll(mask);
-            uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(&s_out, total);
-            start = __shfl(start, 0);
-            if (alive) queue_out[c.seg + start + rank] = slot;
-        }
+        compact_survivors(alive, slot, lane, &s_out, queue_out, c.seg);
     }
     __syncthreads();
     if (threadIdx.x == 0) counts_out[blockIdx.x] = s_out;
 }
 
 // ------------------------------------------------------------------------------------------------------
-// bounce: generate (first bounce only) + extend + shade of one path segment in a single kernel.
-//
-// Compared with the split kernels this keeps the ray and the hit in registers between traversal and shading
-// and drops the per-path radiance from the in-flight state: until a path ends its radiance is, per channel,
-// either +0 or NaN (only emitters add anything else and they end the path, src/material.rs:129-137;
-// `l += beta * 0` turns a channel NaN once beta is not finite, src/renderer.rs:48), so three flag bits next
-// to the draw counter carry it and `radiance[slot]` is written exactly once, when the path ends.
-//   ray_o.w = k (bits 0..23) | NaN flags (bits 24..26);  ray_d.w = depth | sample_in_batch << 16
-// With LDS_SCENE the node and primitive tables are first copied into LDS and traversal reads them there.
+// bounce: generate (first bounce only) + extend + shade of one path segment in a single kernel: the ray and
+// the hit stay in registers between traversal and shading.  With LDS_SCENE the node and primitive tables are
+// first copied into LDS and traversal reads them there.
 // ------------------------------------------------------------------------------------------------------
 template <bool FIRST, bool LDS_SCENE, bool NEED_UV>
 __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
@@ -563,13 +683,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, 
     __shared__ uint32_t s_out;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
-    if (LDS_SCENE) {
-        const uint32_t n4_nodes = 2u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
-        for (uint32_t i = threadIdx.x; i < n4_nodes; i += kBlock) s_scene[i] = nodes[i];
-        for (uint32_t i = threadIdx.x; i < n4_prims; i += kBlock) s_scene[n4_nodes + i] = prims[i];
-        nodes = s_scene;
-        prims = s_scene + n4_nodes;
-    }
+    if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
     if (threadIdx.x == 0) s_out = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -601,43 +715,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, 
             }
             uint32_t c0 = 0, c1 = 0, c2 = 0;
             Closest best = traverse<false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-            const float qnan = __builtin_nanf("");
-            V3 l = V3{(flags & 1u) ? qnan : 0.0f, (flags & 2u) ? qnan : 0.0f, (flags & 4u) ? qnan : 0.0f};
-            if (best.slot == kMissSlot) {
-                l = ld3(P.background); // src/renderer.rs:59-63
-            } else {
-                Surface s = make_surface<NEED_UV>(sc, prims, o, d, best.t, best.slot, best.u, best.v);
-                const MaterialRec m = sc.materials[s.material];
-                V3 emit = V3{0.0f, 0.0f, 0.0f};
-                if (m.kind == 3u) emit = material_color(sc, m, s) * m.param;
-                l = l + beta * emit; // src/renderer.rs:48
-                Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, k);
-                Scatter sr;
-                if (scatter_leaf(sc, m, d, s, rng, sr)) {
-                    V3 f = (sr.attenuation * fabsf(dot(sr.direction, s.normal))) / sr.pdf; // src/renderer.rs:51-54
-                    beta = beta * f;
-                    depth += 1u;
-                    alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
-                    if (alive) {
-                        // a scattering material emits nothing, so l is still +0 or NaN per channel here
-                        flags = (l.x != l.x ? 1u : 0u) | (l.y != l.y ? 2u : 0u) | (l.z != l.z ? 4u : 0u);
-                        st.ray_o[slot] = mk4(s.point, u2f((rng.k & 0xFFFFFFu) | (flags << 24)));
-                        st.ray_d[slot] = mk4(sr.direction, u2f((s_local << 16) | depth));
-                        st.beta[slot] = mk4(beta, 0.0f);
-                    }
-                }
-            }
-            if (!alive) st.radiance[slot] = mk4(l, 0.0f);
+            alive = shade_path<NEED_UV>(sc, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
         }
-        unsigned long long mask = __ballot(alive);
-        if (mask) {
-            uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-            uint32_t total = __popcll(mask);
-            uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(&s_out, total);
-            start = __shfl(start, 0);
-            if (alive) queue_out[c.seg + start + rank] = slot;
-        }
+        compact_survivors(alive, slot, lane, &s_out, queue_out, c.seg);
     }
     __syncthreads();
     if (threadIdx.x == 0) counts_out[blockIdx.x] = s_out;
@@ -732,14 +812,19 @@ void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, 
 }
 
 void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
-                   float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters) {
+                   float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters,
+                   uint32_t lds_bytes) {
     dim3 g(grid), b(kBlock);
     if (!use_bvh)
-        hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
+        hipLaunchKernelGGL(k_extend_world, g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax);
+    else if (counters && lds_bytes)
+        hipLaunchKernelGGL((k_extend<true, true>), g, b, lds_bytes, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
     else if (counters)
-        hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
+        hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
+    else if (lds_bytes)
+        hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
     else
-        hipLaunchKernelGGL((k_extend<false, true>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
+        hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax, counters);
 }
 
 void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,

@@ -220,10 +220,14 @@ def test_rtiow_spheres_with_defocus_and_background(gpu_ctx):
     assert gst.rays_traced / gst.paths > 1.5
 
 
-@pytest.mark.parametrize("pipeline", [F.RT_PIPELINE_SPLIT, F.RT_PIPELINE_FUSED, F.RT_PIPELINE_FUSED_LDS])
+LDS_PIPELINES = (F.RT_PIPELINE_FUSED_LDS, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELINE_SPLIT_LDS)
+
+
+@pytest.mark.parametrize("pipeline", [F.RT_PIPELINE_SPLIT, F.RT_PIPELINE_FUSED, F.RT_PIPELINE_FUSED_LDS,
+                                      F.RT_PIPELINE_HYBRID, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELINE_SPLIT_LDS])
 def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
-    """Split kernels (generate / extend / shade), the fused per-bounce kernel, and the fused kernel with the
-    scene tables in LDS must all give the oracle's sums bit for bit."""
+    """Split kernels (generate / extend / shade), the fused per-bounce kernel, the hybrid of the two, each with
+    the scene tables in HBM or staged in LDS, must all give the oracle's sums bit for bit."""
     ctx = Context(0, flags=F.RT_CTX_TIMING)
     ctx.set_pipeline(pipeline)
     cases = [(cornell_with(cornell), None, RenderSettings(120, 90, 0, 50, 6, mode=F.RT_MODE_LINEAR_MEAN, seed=3,
@@ -234,7 +238,7 @@ def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
     sph, sph_cam = rtiow_final_scene()
     cases.append((sph, sph_cam, RenderSettings(160, 90, 0, 50, 4, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=6,
                                                background_color=(0.7, 0.8, 1.0))))
-    if pipeline != F.RT_PIPELINE_FUSED_LDS:
+    if pipeline not in LDS_PIPELINES:
         lit, lit_cam = lit_teapot(teapot)
         cases.append((lit, lit_cam, RenderSettings(120, 80, 0, 50, 3, mode=F.RT_MODE_LINEAR_MEAN, seed=7)))
     for desc, cs, rs in cases:
@@ -242,7 +246,7 @@ def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
         assert_images_equal(gpu, cpu)
         assert gst.rays_traced == cst.rays_traced
         assert gst.pipeline == pipeline
-    if pipeline == F.RT_PIPELINE_FUSED_LDS:  # tables too large for LDS -> a clear error, not a fault
+    if pipeline in LDS_PIPELINES:  # tables too large for LDS -> a clear error, not a fault
         with pytest.raises(F.RtError) as e:
             render_pair(ctx, teapot, teapot.camera(0), RenderSettings(16, 16, 0, 4, 1))
         assert e.value.code == F.RT_ERR_INVALID_ARGUMENT and "LDS" in e.value.message

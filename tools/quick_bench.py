@@ -21,7 +21,18 @@ def main():
     flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     pipeline = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     max_paths = int(sys.argv[7]) if len(sys.argv) > 7 else 0
-    desc = load_from_gltf(os.path.join(ROOT, "assets", f"{name}.gltf"))
+    from raytracer_amd.scenes import lit_teapot, rtiow_final_scene, triangle_soup
+    bg = (0.0, 0.0, 0.0)
+    if name == "teapot_lit":
+        desc, cs = lit_teapot(load_from_gltf(os.path.join(ROOT, "assets", "teapot.gltf")))
+    elif name == "rtiow":
+        desc, cs = rtiow_final_scene()
+        bg = (0.7, 0.8, 1.0)
+    elif name.startswith("soup"):
+        desc, cs = triangle_soup(int(name[4:]))
+    else:
+        desc = load_from_gltf(os.path.join(ROOT, "assets", f"{name}.gltf"))
+        cs = desc.camera(0)
     ctx = Context(0, flags=flags)
     ctx.set_pipeline(pipeline)
     ctx.set_max_paths(max_paths)
@@ -29,8 +40,8 @@ def main():
     scene = Scene(ctx, desc)
     i = scene.info()
     print(f"scene {name}: {i.num_triangles} tris, {i.num_nodes} nodes, depth {i.depth}, build+upload {time.time()-t0:.3f}s")
-    cam = camera_from_settings(desc.camera(0), w, h)
-    rs = RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=1)
+    cam = camera_from_settings(cs, w, h)
+    rs = RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=1, background_color=bg)
     r = Renderer(cam, scene, rs)
     for rep in range(3):
         t0 = time.time()
@@ -39,7 +50,7 @@ def main():
         st = r.last_stats
         print(f"rep {rep}: wall {dt*1e3:.1f} ms, gpu {st.total_ms:.1f} ms, rays {st.rays_traced} paths {st.paths} "
               f"rays/path {st.rays_traced/st.paths:.3f} -> {st.rays_traced/st.total_ms/1e3:.1f} Mrays/s; "
-              f"pipe {st.pipeline} bounce {st.bounce_ms:.2f} gen {st.generate_ms:.2f} ext {st.extend_ms:.2f} shade {st.shade_ms:.2f} acc {st.accumulate_ms:.2f} ms; "
+              f"pipe {st.pipeline} bounce {st.bounce_ms:.2f} ({st.timed_bounce_rays/1e6:.1f}M) ext_rays {st.timed_extend_rays/1e6:.1f}M gen {st.generate_ms:.2f} ext {st.extend_ms:.2f} shade {st.shade_ms:.2f} acc {st.accumulate_ms:.2f} ms; "
               f"nodes/ray {st.node_visits/max(1,st.rays_traced):.2f} tri/ray {st.triangle_tests/max(1,st.rays_traced):.2f}")
     img /= spp
     fin = np.isfinite(img)
