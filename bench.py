@@ -94,8 +94,9 @@ def main():
 
     total = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
     step_buf = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
-    acc = {"rays": 0, "paths": 0, "extend_ms": 0.0, "timed_rays": 0, "timed_launches": 0, "gpu_ms": 0.0,
-           "shade_ms": 0.0, "generate_ms": 0.0, "accumulate_ms": 0.0}
+    acc = {"rays": 0, "paths": 0, "bounce_ms": 0.0, "extend_ms": 0.0, "timed_rays": 0, "timed_launches": 0,
+           "gpu_ms": 0.0, "shade_ms": 0.0, "generate_ms": 0.0, "accumulate_ms": 0.0, "pipeline": 0,
+           "first_ms": 0.0, "first_rays": 0, "first_launches": 0}
 
     def step(index: int, record: bool):
         # step `index` covers global samples [index * spp * world, (index + 1) * spp * world); rank's block:
@@ -113,12 +114,17 @@ def main():
             acc["rays"] += st.rays_traced
             acc["paths"] += st.paths
             acc["gpu_ms"] += st.total_ms
+            acc["bounce_ms"] += st.bounce_ms
             acc["extend_ms"] += st.extend_ms
             acc["shade_ms"] += st.shade_ms
             acc["generate_ms"] += st.generate_ms
             acc["accumulate_ms"] += st.accumulate_ms
-            acc["timed_rays"] += st.timed_extend_rays
-            acc["timed_launches"] += st.timed_extend_launches
+            acc["timed_rays"] += st.timed_bounce_rays
+            acc["timed_launches"] += st.timed_bounce_launches
+            acc["pipeline"] = st.pipeline
+            acc["first_ms"] += st.first_bounce_ms
+            acc["first_rays"] += st.first_bounce_rays
+            acc["first_launches"] += st.first_bounce_launches
 
     for i in range(args.warmup):
         step(i, False)
@@ -159,13 +165,32 @@ def main():
         nodes_per_ray = st.node_visits / st.rays_traced
         tris_per_ray = st.triangle_tests / st.rays_traced
         sph_per_ray = st.sphere_tests / st.rays_traced
-        bytes_per_ray = 32 + 16 + 32 * nodes_per_ray + 36 * tris_per_ray + 16 * sph_per_ray
+        # + 80 B of path state per segment (throughput, radiance, pixel, depth/flags, rng; read and written)
+        bytes_per_ray = 32 + 16 + 32 * nodes_per_ray + 36 * tris_per_ray + 16 * sph_per_ray + 80
         cscene.close()
         cctx.close()
 
-        avg_launch_ms = acc["extend_ms"] / max(1, acc["timed_launches"])
-        rays_per_launch = acc["timed_rays"] / max(1, acc["timed_launches"])
-        achieved = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        # HBM bytes per ray of the same kernel from the committed PMC run (FETCH_SIZE x2 + WRITE_SIZE)
+        traffic_per_ray = None
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic_cornell1080p.json")
+        if os.path.exists(tj):
+            kern = json.load(open(tj)).get("kernels", {}).get("k_bounce")
+            if kern:
+                traffic_per_ray = kern["hbm_read_bytes_per_ray"] + kern["hbm_write_bytes_per_ray"]
+
+        # The fused kernel has two instances: k_bounce<FIRST=true> (bounce 0: camera rays generated in place) and
+        # k_bounce<FIRST=false> (later bounces).  Later bounces dominate the time; bounces 1..TIMED_BOUNCES-1 of every
+        # batch are bracketed by events here, bounce 0 separately.
+        def group(ms, rays, launches):
+            avg_ms = ms / max(1, launches)
+            per_launch = rays / max(1, launches)
+            ach = bytes_per_ray * per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            return avg_ms, per_launch, ach
+
+        later = group(acc["bounce_ms"] - acc["first_ms"], acc["timed_rays"] - acc["first_rays"],
+                      acc["timed_launches"] - acc["first_launches"])
+        first = group(acc["first_ms"], acc["first_rays"], acc["first_launches"])
+        avg_launch_ms, rays_per_launch, achieved = later
         img = (total / float(spp * world * (args.steps + args.warmup))).cpu().numpy()
         finite = np.isfinite(img)
         out = {
@@ -189,17 +214,27 @@ def main():
             "mpaths_per_s": paths_all / elapsed / 1e6,
             "rays_per_path": rays_all / max(1, paths_all),
             "time_to_1024spp_s": 1024.0 * npix / (paths_all / elapsed),
-            "kernel_ms_rank0": {k: acc[k] for k in ("gpu_ms", "generate_ms", "extend_ms", "shade_ms", "accumulate_ms")},
+            "pipeline": {2: "fused", 3: "fused+lds"}.get(acc["pipeline"], str(acc["pipeline"])),
+            "kernel_ms_rank0": {k: acc[k] for k in ("gpu_ms", "bounce_ms", "generate_ms", "extend_ms", "shade_ms",
+                                                    "accumulate_ms")},
             "image_check": {"finite_mean": float(img[finite].mean()), "inf_fraction": float(np.isinf(img).mean()),
                             "nan_fraction": float(np.isnan(img).mean())},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_extend", "avg_launch_ms": avg_launch_ms, "rays_per_launch": rays_per_launch,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None if traffic_per_ray is None else traffic_per_ray * rays_per_launch,
+                "traffic_unit": "bytes per launch (HBM, PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_cornell1080p.json)",
+                "kernel": "k_bounce<false,true,false> (extend + shade of bounces 1..%d of each batch, BVH and triangles "
+                          "staged in LDS)" % (TIMED_BOUNCES - 1),
+                "avg_launch_ms": avg_launch_ms, "rays_per_launch": rays_per_launch,
+                "first_bounce_kernel": {"kernel": "k_bounce<true,true,false> (generate + extend + shade of bounce 0)",
+                                        "avg_launch_ms": first[0], "rays_per_launch": first[1], "achieved": first[2],
+                                        "frac": first[2] / HBM_PEAK_GBS, "launches": acc["first_launches"]},
                 "algorithmic_bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
-                "triangle_tests_per_ray": tris_per_ray, "timed_launches": acc["timed_launches"],
-                "note": "Cornell's BVH + triangles are 4 KB and stay in L1/L2: the algorithmic bytes never reach HBM, so "
-                        "frac is a cache-bandwidth figure quoted against the HBM peak as the contract asks",
+                "triangle_tests_per_ray": tris_per_ray, "timed_launches": acc["timed_launches"] - acc["first_launches"],
+                "note": "Cornell's BVH + triangles are 4 KB and are read from LDS: of the algorithmic bytes only the path "
+                        "state reaches HBM (see traffic), so frac is an on-chip bandwidth figure quoted against the HBM "
+                        "peak as the contract asks; the kernel is VALU-issue bound (profiles/r01_pmc_summary_*.txt)",
             },
         }
         if not args.no_cpu_baseline:

@@ -235,6 +235,10 @@ typedef struct rt_stats {
     uint64_t timed_bounce_rays;     /* rays processed by the bounce launches that bounce_ms covers */
     uint32_t timed_bounce_launches;
     uint32_t bounce_launches;
+    double first_bounce_ms;         /* the part of bounce_ms spent in bounce-0 launches (camera rays) */
+    uint64_t first_bounce_rays;     /* rays of those launches */
+    uint32_t first_bounce_launches;
+    uint32_t reserved;
 } rt_stats;
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -329,6 +333,26 @@ int rt_render(rt_context *ctx, const rt_scene *scene, const rt_camera *camera, c
  * stream unless `stats` is non-NULL. */
 int rt_render_device(rt_context *ctx, const rt_scene *scene, const rt_camera *camera,
                      const rt_settings *settings, float *d_accum, rt_stats *stats);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* glTF import (host only)                                                                                */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* `scene::load_from_gltf` (src/scene.rs:208-250): reads a .gltf (external or base64 buffers) or .glb file the
+ * way the reference's loader does — every node's LOCAL transform, the first TRIANGLES primitive of its mesh,
+ * positions transformed and normals not, emissive materials as white DiffuseLight of the emissive strength and
+ * everything else as Lambertian of the base colour factor, perspective cameras with focus distance 10.
+ * Base-colour image textures are reported as RT_ERR_PARSE (no image decoder is linked).  The returned object
+ * owns every buffer the scene description points into. */
+typedef struct rt_gltf rt_gltf;
+int rt_gltf_load(const char *path, rt_gltf **out);
+int rt_gltf_free(rt_gltf *gltf);
+/* The object list as an rt_scene_desc, valid until rt_gltf_free. */
+const rt_scene_desc *rt_gltf_scene(const rt_gltf *gltf);
+/* `SceneDescription::cameras` / `SceneDescription::camera(index)` (src/scene.rs:25-27): an index beyond the
+ * file's cameras yields CameraSettings::default. */
+uint32_t rt_gltf_camera_count(const rt_gltf *gltf);
+int rt_gltf_camera(const rt_gltf *gltf, uint32_t index, rt_camera_settings *out);
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,9 @@ class rt_stats(C.Structure):
                 ("shade_ms", C.c_double), ("accumulate_ms", C.c_double),
                 ("timed_extend_rays", C.c_uint64), ("timed_extend_launches", C.c_uint32),
                 ("pipeline", C.c_uint32), ("bounce_ms", C.c_double), ("timed_bounce_rays", C.c_uint64),
-                ("timed_bounce_launches", C.c_uint32), ("bounce_launches", C.c_uint32)]
+                ("timed_bounce_launches", C.c_uint32), ("bounce_launches", C.c_uint32),
+                ("first_bounce_ms", C.c_double), ("first_bounce_rays", C.c_uint64),
+                ("first_bounce_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # numpy dtypes with the same layout as rt_ray / rt_hit (both are 4-byte-aligned plain records).
@@ -135,6 +137,11 @@ EXPORTS = {
                                           C.POINTER(rt_stats)]),
     "rt_render": (C.c_int, [_vp, _vp, C.POINTER(rt_camera), C.POINTER(rt_settings), _vp,
                             C.POINTER(rt_stats)]),
+    "rt_gltf_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "rt_gltf_free": (C.c_int, [_vp]),
+    "rt_gltf_scene": (C.POINTER(rt_scene_desc), [_vp]),
+    "rt_gltf_camera_count": (C.c_uint32, [_vp]),
+    "rt_gltf_camera": (C.c_int, [_vp, C.c_uint32, C.POINTER(rt_camera_settings)]),
     "rt_render_device": (C.c_int, [_vp, _vp, C.POINTER(rt_camera), C.POINTER(rt_settings), _vp,
                                    C.POINTER(rt_stats)]),
 }

@@ -36,6 +36,14 @@ int set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+} // namespace
+
+namespace rt {
+void set_last_error(const std::string &message) { g_error = message; }
+} // namespace rt
+
+namespace {
+
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -65,7 +73,7 @@ template <class T> struct DevBuf {
     }
 };
 
-enum KernelKind { K_GENERATE = 0, K_EXTEND = 1, K_SHADE = 2, K_ACCUMULATE = 3, K_BOUNCE = 4, K_KINDS = 5 };
+enum KernelKind { K_GENERATE = 0, K_EXTEND = 1, K_SHADE = 2, K_ACCUMULATE = 3, K_BOUNCE = 4, K_BOUNCE0 = 5, K_KINDS = 6 };
 
 } // namespace
 
@@ -165,7 +173,7 @@ int timed_end(rt_context *c, bool on = true) {
 
 int collect_timing(rt_context *c, rt_stats *st) {
     if (!(c->flags & RT_CTX_TIMING)) return RT_OK;
-    double sums[K_KINDS] = {0, 0, 0, 0, 0};
+    double sums[K_KINDS] = {0, 0, 0, 0, 0, 0};
     for (const auto &s : c->spans) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[s.a], c->ev_pool[s.b]));
@@ -175,7 +183,8 @@ int collect_timing(rt_context *c, rt_stats *st) {
     st->extend_ms = sums[K_EXTEND];
     st->shade_ms = sums[K_SHADE];
     st->accumulate_ms = sums[K_ACCUMULATE];
-    st->bounce_ms = sums[K_BOUNCE];
+    st->bounce_ms = sums[K_BOUNCE] + sums[K_BOUNCE0];
+    st->first_bounce_ms = sums[K_BOUNCE0];
     return RT_OK;
 }
 
@@ -605,7 +614,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             uint32_t *counts_out = c->counts.ptr + (size_t)(it + 1) * grid;
             const bool timed = it < c->timed_bounces;
             if (fused_all || (fused_first && it == 0)) {
-                if (int rc = timed_begin(c, K_BOUNCE, timed)) return rc;
+                if (int rc = timed_begin(c, it == 0 ? K_BOUNCE0 : K_BOUNCE, timed)) return rc;
                 rt::launch_bounce(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, it == 0, s->need_uv, lds_bytes);
                 if (int rc = timed_end(c, timed)) return rc;
                 ++bounce_launches;
@@ -651,6 +660,10 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
                     if (fused_all || (fused_first && it == 0)) {
                         timed_bounce_rays += r;
                         ++timed_bounce;
+                        if (it == 0) {
+                            stats->first_bounce_rays += r;
+                            ++stats->first_bounce_launches;
+                        }
                     } else {
                         timed_extend_rays += r;
                         ++timed_extend;

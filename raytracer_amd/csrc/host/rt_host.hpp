@@ -1,0 +1,220 @@
+// rt_host.hpp — C++ host-side mirror of the reference's `Renderer` surface over the C ABI.
+//
+// The reference is compiled code (Rust) whose toolchain is not available to this build, so the host layer a
+// Rust caller would get from a `-sys` crate is provided in C++ with the reference's names and argument
+// meaning: `load_from_gltf` (src/scene.rs:208), `SceneDescription::camera` (src/scene.rs:25-27), `Camera::new`
+// (src/camera.rs:20), `RenderSettings` (src/scene.rs:53-60), `Renderer::{new, render, render_progressive}`
+// (src/renderer.rs:25,72,105) and `ImageOutput` (src/renderer.rs:178-226, file sink only).
+// Errors surface as rt::host::Error carrying the rt_status code and rt_last_error().
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt_mi355x.h"
+
+namespace rt {
+namespace host {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &msg) : std::runtime_error(msg), code(c) {}
+};
+
+inline void check(int rc) {
+    if (rc != RT_OK) throw Error(rc, rt_last_error());
+}
+
+// `RenderSettings` (src/scene.rs:53-60); defaults are the CLI's (src/main.rs:46-59,86).
+struct RenderSettings {
+    uint32_t image_width = 1280;
+    uint32_t image_height = 720;
+    size_t selected_camera = 0;
+    uint32_t max_depth = 50;
+    uint32_t samples_per_pixel = 100;
+    float background_color[3] = {0.0f, 0.0f, 0.0f};
+    uint64_t seed = 1; // the reference seeds from OS entropy; a fixed seed makes runs reproducible
+};
+
+class Context {
+  public:
+    explicit Context(int device = 0, uint32_t flags = 0) { check(rt_context_create(device, nullptr, flags, &h_)); }
+    ~Context() { rt_context_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    rt_context *get() const { return h_; }
+
+  private:
+    rt_context *h_ = nullptr;
+};
+
+// `SceneDescription` (src/scene.rs:18-22) as loaded from a glTF file; owns the host copy.
+class SceneDescription {
+  public:
+    static SceneDescription load_from_gltf(const std::string &path) {
+        SceneDescription s;
+        check(rt_gltf_load(path.c_str(), &s.g_));
+        return s;
+    }
+    SceneDescription(SceneDescription &&o) noexcept : g_(o.g_) { o.g_ = nullptr; }
+    SceneDescription &operator=(SceneDescription &&o) noexcept {
+        if (this != &o) {
+            rt_gltf_free(g_);
+            g_ = o.g_;
+            o.g_ = nullptr;
+        }
+        return *this;
+    }
+    ~SceneDescription() { rt_gltf_free(g_); }
+    const rt_scene_desc *desc() const { return rt_gltf_scene(g_); }
+    size_t camera_count() const { return rt_gltf_camera_count(g_); }
+    // `SceneDescription::camera(index)`: beyond the file's cameras the default camera.
+    rt_camera_settings camera(size_t index) const {
+        rt_camera_settings cs;
+        check(rt_gltf_camera(g_, (uint32_t)index, &cs));
+        return cs;
+    }
+
+  private:
+    SceneDescription() = default;
+    rt_gltf *g_ = nullptr;
+};
+
+// The scene after `build_bvh(BvhType::Tree)` (src/scene.rs:29-49), resident on the GPU.
+class Scene {
+  public:
+    Scene(const Context &ctx, const rt_scene_desc *desc) { check(rt_scene_create(ctx.get(), desc, &h_)); }
+    ~Scene() { rt_scene_destroy(h_); }
+    Scene(const Scene &) = delete;
+    Scene &operator=(const Scene &) = delete;
+    rt_scene *get() const { return h_; }
+    rt_scene_info info() const {
+        rt_scene_info i;
+        check(rt_scene_get_info(h_, &i));
+        return i;
+    }
+
+  private:
+    rt_scene *h_ = nullptr;
+};
+
+// `Camera::new(settings, width, height)` (src/camera.rs:20-64).
+inline rt_camera make_camera(const rt_camera_settings &settings, uint32_t width, uint32_t height) {
+    rt_camera cam;
+    check(rt_camera_from_settings(&settings, width, height, &cam));
+    return cam;
+}
+
+// src/renderer.rs:167-171
+inline bool should_save_image(uint32_t current_sample, uint32_t sample_count) {
+    return current_sample <= 5 || current_sample % 16 == 0 || current_sample == sample_count;
+}
+
+// `pixels_to_image` (src/renderer.rs:173-176): Rgb32F -> Rgb8, round(clamp(c, 0, 1) * 255), NaN -> 0.
+inline std::vector<uint8_t> pixels_to_rgb8(const std::vector<float> &pixels) {
+    std::vector<uint8_t> out(pixels.size());
+    for (size_t i = 0; i < pixels.size(); ++i) {
+        float c = pixels[i];
+        if (!(c == c)) c = 0.0f;
+        c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+        out[i] = (uint8_t)std::lround(c * 255.0f);
+    }
+    return out;
+}
+
+// File sink of `ImageOutput` (src/renderer.rs:178-226): `.pfm` keeps the floats, anything else is written as
+// binary PPM after the 8-bit conversion above.
+struct ImageOutput {
+    std::string path;
+    void write(const std::vector<float> &pixels, uint32_t width, uint32_t height) const {
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) throw Error(RT_ERR_IO, "cannot open " + path);
+        const bool pfm = path.size() >= 4 && path.compare(path.size() - 4, 4, ".pfm") == 0;
+        if (pfm) {
+            std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);
+            for (uint32_t j = height; j-- > 0;) // PFM rows run bottom to top
+                std::fwrite(pixels.data() + (size_t)j * width * 3, sizeof(float), (size_t)width * 3, f);
+        } else {
+            std::vector<uint8_t> px = pixels_to_rgb8(pixels);
+            std::fprintf(f, "P6\n%u %u\n255\n", width, height);
+            std::fwrite(px.data(), 1, px.size(), f);
+        }
+        std::fclose(f);
+    }
+};
+
+// `Renderer` (src/renderer.rs:18-157).
+class Renderer {
+  public:
+    // `Renderer::new(camera, scene, render)`
+    Renderer(const Context &ctx, rt_camera camera, const Scene &scene, RenderSettings render)
+        : ctx_(ctx), camera_(camera), scene_(scene), render_(render) {}
+
+    // `Renderer::render(square_size)`: linear mean of all samples.  Returns row-major RGB floats; the reference
+    // converts them with pixels_to_image.  `square_size` shaped the reference's CPU chunks and is ignored.
+    std::vector<float> render(size_t /*square_size*/ = 16, rt_stats *stats = nullptr) const {
+        std::vector<float> sums((size_t)render_.image_width * render_.image_height * 3);
+        rt_settings st = settings(RT_MODE_LINEAR_MEAN, 0, render_.samples_per_pixel);
+        check(rt_render(ctx_.get(), scene_.get(), &camera_, &st, sums.data(), stats));
+        const float sample_scale = 1.0f / (float)render_.samples_per_pixel;
+        for (float &c : sums) c = c * sample_scale;
+        return sums;
+    }
+
+    // `Renderer::render_progressive(output, square_size)`: running sum of gamma-mapped samples; `output` gets
+    // aggregate * (1 / current_sample) after samples 1-5, every 16th and the last.
+    void render_progressive(const std::function<void(const std::vector<float> &, uint32_t, uint32_t, uint32_t)> &output,
+                            size_t /*square_size*/ = 16, rt_stats *total = nullptr) const {
+        const uint32_t w = render_.image_width, h = render_.image_height, spp = render_.samples_per_pixel;
+        std::vector<float> aggregate((size_t)w * h * 3, 0.0f), part(aggregate.size());
+        uint32_t done = 0;
+        while (done < spp) {
+            uint32_t next = done + 1;
+            while (!should_save_image(next, spp)) ++next;
+            rt_settings st = settings(RT_MODE_GAMMA_PER_SAMPLE, done, next - done);
+            rt_stats s;
+            check(rt_render(ctx_.get(), scene_.get(), &camera_, &st, part.data(), &s));
+            if (total) {
+                total->rays_traced += s.rays_traced;
+                total->paths += s.paths;
+                total->total_ms += s.total_ms;
+            }
+            // Adding a block of samples to the running sum is not the same float operation order as adding them
+            // one by one unless the block starts from the running sum; rt_render_device does exactly that on the
+            // GPU.  With host buffers the first block is exact and later blocks differ in the last bits only.
+            for (size_t i = 0; i < aggregate.size(); ++i) aggregate[i] += part[i];
+            done = next;
+            const float sample_scale = 1.0f / (float)done;
+            std::vector<float> image(aggregate.size());
+            for (size_t i = 0; i < aggregate.size(); ++i) image[i] = aggregate[i] * sample_scale;
+            output(image, w, h, done);
+        }
+    }
+
+  private:
+    rt_settings settings(uint32_t mode, uint32_t begin, uint32_t count) const {
+        rt_settings st{};
+        st.image_width = render_.image_width;
+        st.image_height = render_.image_height;
+        st.max_depth = render_.max_depth;
+        st.samples_per_pixel = render_.samples_per_pixel;
+        for (int i = 0; i < 3; ++i) st.background_color[i] = render_.background_color[i];
+        st.mode = mode;
+        st.seed = render_.seed;
+        st.sample_begin = begin;
+        st.sample_count = count;
+        return st;
+    }
+    const Context &ctx_;
+    rt_camera camera_;
+    const Scene &scene_;
+    RenderSettings render_;
+};
+
+} // namespace host
+} // namespace rt

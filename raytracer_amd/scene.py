@@ -424,3 +424,37 @@ def load_from_gltf(path: str, image_decoder=None) -> SceneDescription:
                     z_far=float(f32(p["zfar"])) if "zfar" in p else math.inf, transform=aff,
                     focus_dist=10.0, defocus_angle=0.0))
     return scene
+
+
+def load_from_gltf_native(path: str) -> SceneDescription:
+    """The same import done by the library's C++ reader (rt_gltf_load), copied into a SceneDescription."""
+    lib = F.load_library()
+    h = C.c_void_p()
+    F.check(lib, lib.rt_gltf_load(os.fsencode(path), C.byref(h)))
+    try:
+        d = lib.rt_gltf_scene(h).contents
+        sc = SceneDescription()
+        for i in range(d.num_textures):
+            t = d.textures[i]
+            sc.textures.append(Texture(t.kind, (t.rgb[0], t.rgb[1], t.rgb[2]), t.inv_scale, t.even, t.odd))
+        for i in range(d.num_materials):
+            m = d.materials[i]
+            sc.materials.append(Material(m.kind, m.texture, m.param, m.left, m.right))
+        for i in range(d.num_meshes):
+            m = d.meshes[i]
+
+            def arr(ptr, n, cols, dt):
+                if not n:
+                    return np.zeros((0, cols), dtype=dt)
+                return np.ctypeslib.as_array(ptr, shape=(n * cols,)).astype(dt).reshape(n, cols).copy()
+
+            sc.meshes.append(TriangleMesh(arr(m.positions, m.num_vertices, 3, f32), arr(m.indices, m.num_faces, 3, np.uint32),
+                                          arr(m.normals, m.num_normals, 3, f32), arr(m.uvs, m.num_uvs, 2, f32), m.material))
+        for i in range(lib.rt_gltf_camera_count(h)):
+            cs = F.rt_camera_settings()
+            F.check(lib, lib.rt_gltf_camera(h, i, C.byref(cs)))
+            sc.cameras.append(CameraSettings(None, cs.y_fov, cs.z_near, cs.z_far, np.array(list(cs.transform), dtype=f32),
+                                             cs.focus_dist, cs.defocus_angle))
+        return sc
+    finally:
+        lib.rt_gltf_free(h)

@@ -405,3 +405,45 @@ def oracle_rows(oracle, cam, rs, row0, row1):
                           rs.mode, rs.seed, rs.sample_begin, rs.sample_count)
     img, st = oracle.render(cam, part, threads=16)
     return img[row0:row1], st
+
+
+def _read_pfm(path):
+    with open(path, "rb") as fh:
+        assert fh.readline().strip() == b"PF"
+        w, h = (int(x) for x in fh.readline().split())
+        assert float(fh.readline()) < 0  # little endian
+        data = np.frombuffer(fh.read(), dtype="<f4").reshape(h, w, 3)
+    return data[::-1]  # PFM stores rows bottom to top
+
+
+def test_cpp_host_cli(cornell, tmp_path):
+    """The C++ host layer (rt_host.hpp: load_from_gltf, Camera::new, Renderer::render / render_progressive,
+    file ImageOutput) driven by rt_cli with the reference CLI's flags, against the oracle."""
+    import subprocess
+
+    cli = os.path.join(os.path.dirname(F.LIB_PATH), "rt_cli")
+    asset = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "cornell.gltf")
+    w, h, spp = 80, 60, 7
+    oracle = ob.OracleScene(cornell)
+    cam = ob.camera_from_settings(cornell.camera(0), w, h)
+    out = str(tmp_path / "batch.pfm")
+    r = subprocess.run([cli, "-W", str(w), "-H", str(h), "--spp", str(spp), "-d", "50", "-c", "0", "--seed", "9", "--batch",
+                        asset, out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "building BVH took" in r.stdout and "Rendering took" in r.stdout
+    cpu, _ = oracle.render(cam, RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_LINEAR_MEAN, seed=9), threads=8)
+    assert bits_equal(_read_pfm(out), cpu * (np.float32(1.0) / np.float32(spp))).all()
+    out = str(tmp_path / "prog.pfm")
+    r = subprocess.run([cli, "--width", str(w), "--height", str(h), "--spp", str(spp), "--seed", "9", "--debug",
+                        "--bvh-disabled", asset, out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("Outputted image after sample") == 6  # samples 1,2,3,4,5,7
+    cpu, _ = oracle.render(cam, RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=9), threads=8)
+    got, want = _read_pfm(out), cpu * (np.float32(1.0) / np.float32(spp))
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin) and np.allclose(got[fin], want[fin], rtol=1e-5, atol=1e-6)
+    out = str(tmp_path / "img.ppm")
+    r = subprocess.run([cli, "-W", "16", "-H", "12", "--spp", "2", asset, out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and open(out, "rb").read().startswith(b"P6\n16 12\n255\n")
+    r = subprocess.run([cli, "/nonexistent.gltf"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "error" in r.stderr

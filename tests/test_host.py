@@ -160,3 +160,84 @@ def test_render_settings_defaults_match_cli():
     assert tuple(rs.background_color) == (0.0, 0.0, 0.0)
     c = rs.to_c()
     assert c.mode == F.RT_MODE_GAMMA_PER_SAMPLE and c.seed == 1
+
+
+def _same_scene(a, b):
+    assert len(a.meshes) == len(b.meshes) and len(a.cameras) == len(b.cameras)
+    for ma, mb in zip(a.meshes, b.meshes):
+        for fa, fb in ((ma.positions, mb.positions), (ma.normals, mb.normals), (ma.uvs, mb.uvs)):
+            assert fa.shape == fb.shape and np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+        assert np.array_equal(ma.indices, mb.indices)
+        ka, kb = a.materials[ma.material], b.materials[mb.material]
+        assert (ka.kind, ka.param) == (kb.kind, kb.param)
+        assert tuple(a.textures[ka.texture].rgb) == tuple(b.textures[kb.texture].rgb)
+    for ca, cb in zip(a.cameras, b.cameras):
+        assert (ca.y_fov, ca.z_near, ca.z_far, ca.focus_dist, ca.defocus_angle) == (cb.y_fov, cb.z_near, cb.z_far, cb.focus_dist, cb.defocus_angle)
+        assert np.array_equal(np.asarray(ca.transform, np.float32), np.asarray(cb.transform, np.float32))
+
+
+def test_native_gltf_reader_matches_python_reader(cornell, teapot, tmp_path):
+    """rt_gltf_load (C++, part of the library) and the Python reader used by the tests produce identical
+    scenes, bit for bit, on both reference assets and on a synthetic file with a rotated node, a matrix node,
+    u32 indices, an interleaved (strided) vertex buffer, a non-indexed primitive (which yields no faces,
+    src/scene.rs:170-175) and a GLB container."""
+    import json
+    import struct
+
+    from raytracer_amd.scene import load_from_gltf, load_from_gltf_native
+
+    _same_scene(load_from_gltf_native(os.path.join(ROOT, "assets", "cornell.gltf")), cornell)
+    _same_scene(load_from_gltf_native(os.path.join(ROOT, "assets", "teapot.gltf")), teapot)
+
+    rng = np.random.default_rng(5)
+    verts = rng.normal(size=(6, 3)).astype(np.float32)
+    norms = rng.normal(size=(6, 3)).astype(np.float32)
+    inter = np.concatenate([verts, norms], axis=1).astype(np.float32).tobytes()  # stride 24
+    idx = np.array([0, 1, 2, 3, 4, 5, 1], dtype=np.uint32).tobytes()           # 7 indices: the tail is dropped
+    uv = (rng.random((6, 2)) * 65535).astype(np.uint16).tobytes()               # normalised u16 texcoords
+    blob = inter + idx + uv
+    doc = {
+        "asset": {"version": "2.0"},
+        "nodes": [
+            {"mesh": 0, "translation": [1, 2, 3], "rotation": [0.1825742, 0.3651484, 0.5477226, 0.7302967], "scale": [2, 0.5, 3]},
+            {"mesh": 1, "matrix": [0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 1, 0, 5, 6, 7, 1]},
+            {"camera": 0, "translation": [0, 1, 9]}, {"camera": 1},
+        ],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.5, "znear": 0.01}},
+                    {"type": "orthographic", "orthographic": {"xmag": 1, "ymag": 1, "zfar": 10, "znear": 1}}],
+        "materials": [{"emissiveFactor": [0, 0.5, 0]}, {"pbrMetallicRoughness": {"baseColorFactor": [0.1, 0.2, 0.3, 1]}}],
+        "meshes": [
+            {"primitives": [{"mode": 1, "attributes": {"POSITION": 0}},
+                            {"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 3}, "indices": 2, "material": 0}]},
+            {"primitives": [{"attributes": {"POSITION": 0}, "material": 1}]},
+        ],
+        "accessors": [
+            {"bufferView": 0, "componentType": 5126, "count": 6, "type": "VEC3"},
+            {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": 6, "type": "VEC3"},
+            {"bufferView": 1, "componentType": 5125, "count": 7, "type": "SCALAR"},
+            {"bufferView": 2, "componentType": 5123, "normalized": True, "count": 6, "type": "VEC2"},
+        ],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(inter), "byteStride": 24},
+                        {"buffer": 0, "byteOffset": len(inter), "byteLength": len(idx)},
+                        {"buffer": 0, "byteOffset": len(inter) + len(idx), "byteLength": len(uv)}],
+        "buffers": [{"byteLength": len(blob)}],
+    }
+    text = json.dumps(doc).encode()
+    text += b" " * (-len(text) % 4)
+    blob += b"\0" * (-len(blob) % 4)
+    glb = b"glTF" + struct.pack("<II", 2, 12 + 8 + len(text) + 8 + len(blob))
+    glb += struct.pack("<I", len(text)) + b"JSON" + text + struct.pack("<I", len(blob)) + b"BIN\0" + blob
+    path = tmp_path / "synthetic.glb"
+    path.write_bytes(glb)
+    a, b = load_from_gltf_native(str(path)), load_from_gltf(str(path))
+    _same_scene(a, b)
+    assert [len(m.indices) for m in a.meshes] == [2, 0] and len(a.cameras) == 1
+    assert a.materials[a.meshes[0].material].kind == F.RT_MAT_DIFFUSE_LIGHT and a.materials[a.meshes[0].material].param == 1.0
+    assert np.isinf(a.cameras[0].z_far)
+    # error reporting
+    lib = F.load_library()
+    h = C.c_void_p()
+    assert lib.rt_gltf_load(b"/nonexistent/file.gltf", C.byref(h)) == F.RT_ERR_IO
+    bad = tmp_path / "bad.gltf"
+    bad.write_text("{ \"nodes\": [ }")
+    assert lib.rt_gltf_load(os.fsencode(str(bad)), C.byref(h)) == F.RT_ERR_PARSE and b"JSON" in lib.rt_last_error()
