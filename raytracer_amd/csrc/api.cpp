@@ -118,6 +118,7 @@ struct rt_scene {
     std::vector<uint32_t> prim_of_slot;
     rt_scene_info info{};
     bool need_uv = false;
+    bool has_mix = false;
 };
 
 namespace {
@@ -325,7 +326,6 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
         return set_error(RT_ERR_INVALID_ARGUMENT, "scene build failed: %s", e.what());
     }
     if (rc) return set_error(rc, "%s", err.c_str());
-    if (hs.has_mix) return set_error(RT_ERR_UNSUPPORTED, "Mix materials are not supported by the device path yet");
 
     DeviceGuard guard(c->device);
     rt_scene *s = new (std::nothrow) rt_scene();
@@ -348,6 +348,7 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
     s->dev.n_materials = (uint32_t)hs.materials.size();
     s->dev.n_textures = (uint32_t)hs.textures.size();
     s->need_uv = hs.need_uv;
+    s->has_mix = hs.has_mix;
     s->prim_of_slot.swap(hs.prim_of_slot);
     s->info.num_triangles = hs.n_triangles;
     s->info.num_spheres = hs.n_spheres;
@@ -583,7 +584,8 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     uint32_t pipeline = c->pipeline;
     if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 40u * 1024u ? RT_PIPELINE_FUSED_LDS : RT_PIPELINE_FUSED;
     const bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS;
-    if (count) pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
+    // Mix materials are evaluated by the split shade kernel only.
+    if (count || s->has_mix) pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     if (lds && table_bytes > 64u * 1024u)
         return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
                          (unsigned long long)table_bytes);
@@ -624,7 +626,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
                                   count ? c->counters.ptr : nullptr, lds_bytes);
                 if (int rc = timed_end(c, timed)) return rc;
                 if (int rc = timed_begin(c, K_SHADE, timed)) return rc;
-                rt::launch_shade(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, s->need_uv);
+                rt::launch_shade(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, s->need_uv, s->has_mix);
                 if (int rc = timed_end(c, timed)) return rc;
                 ++extend_launches;
                 ++shade_launches;

@@ -20,8 +20,9 @@ void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float
 
 // Shades the items of `q`; block b appends its surviving slots at queue_out[b * q.cap ...] and stores their
 // number in counts_out[b].
+// `has_mix` selects the variant that evaluates Mix materials (only the split kernels carry that code).
 void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv);
+                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv, bool has_mix);
 
 // One whole path segment per item: camera ray generation (`first`), closest hit, shading, compaction.
 // `lds_bytes` != 0 stages the node and primitive tables in that many bytes of LDS (2 * 16 * n_nodes +

@@ -358,6 +358,42 @@ __device__ __forceinline__ bool scatter_leaf(const SceneDev &sc, const MaterialR
     }
 }
 
+// Mix::scatter and ScatterResult::mix (src/material.rs:186-204,21-30; random::choose, src/random.rs:24-31):
+// factor 1 -> right, factor 0 -> left, otherwise BOTH children scatter (each consuming its random draws, left
+// first), then one more draw picks whose ray continues while the attenuations are blended and the pdf is
+// dropped.  Children may be Mix materials themselves; DEPTH bounds the nesting (validated at scene creation).
+template <int DEPTH>
+__device__ __noinline__ bool scatter_material(const SceneDev &sc, int32_t mi, V3 d, const Surface &s, Rng &rng,
+                                              Scatter &out) {
+    const MaterialRec m = sc.materials[mi];
+    if (m.kind != 4u) return scatter_leaf(sc, m, d, s, rng, out);
+    if constexpr (DEPTH == 0) {
+        return false; // unreachable: nesting depth is validated on the host
+    } else {
+        if (m.param == 1.0f) return scatter_material<DEPTH - 1>(sc, m.right, d, s, rng, out);
+        if (m.param == 0.0f) return scatter_material<DEPTH - 1>(sc, m.left, d, s, rng, out);
+        Scatter l, r;
+        const bool got_l = scatter_material<DEPTH - 1>(sc, m.left, d, s, rng, l);
+        const bool got_r = scatter_material<DEPTH - 1>(sc, m.right, d, s, rng, r);
+        if (got_l && got_r) {
+            const float n = rng_random(rng);
+            out.direction = n < m.param ? l.direction : r.direction;
+            out.attenuation = l.attenuation * m.param + r.attenuation * (1.0f - m.param);
+            out.pdf = 1.0f;
+            return true;
+        }
+        if (got_r) {
+            out = r;
+            return true;
+        }
+        if (got_l) {
+            out = l;
+            return true;
+        }
+        return false;
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------------------
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_world(SceneDev sc, const floa
 // shading: the body of Renderer::ray_color's loop after `world.hit` (src/renderer.rs:46-66) for one path.
 // Writes the path's next state (and returns true) or its final radiance (and returns false).
 // ------------------------------------------------------------------------------------------------------
-template <bool NEED_UV>
+template <bool NEED_UV, bool HAS_MIX>
 __device__ __forceinline__ bool shade_path(const SceneDev &sc, const float4 *__restrict__ prims, const RenderParams &P,
                                            const PathState &st, uint32_t slot, V3 o, V3 d, V3 beta, uint32_t k,
                                            uint32_t flags, uint32_t depth, uint32_t s_local, uint32_t pixel,
@@ -605,7 +641,9 @@ __device__ __forceinline__ bool shade_path(const SceneDev &sc, const float4 *__r
         l = l + beta * emit;
         Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, k);
         Scatter sr;
-        if (scatter_leaf(sc, m, d, s, rng, sr)) {
+        const bool scattered = HAS_MIX ? scatter_material<4>(sc, (int32_t)s.material, d, s, rng, sr)
+                                       : scatter_leaf(sc, m, d, s, rng, sr);
+        if (scattered) {
             V3 f = (sr.attenuation * fabsf(dot(sr.direction, s.normal))) / sr.pdf; // src/renderer.rs:51-54
             beta = beta * f;
             depth += 1u;
@@ -640,7 +678,7 @@ __device__ __forceinline__ void compact_survivors(bool alive, uint32_t slot, uin
 }
 
 // shade: every queued path whose hit record extend has written.
-template <bool NEED_UV>
+template <bool NEED_UV, bool HAS_MIX>
 __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, PathState st, QueueView q,
                                                   uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out) {
     __shared__ uint32_t s_out;
@@ -662,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
             float4 b4 = st.beta[slot];
             Closest best{h.x, f2u(h.y), h.z, h.w};
             const uint32_t s_local = f2u(d4.w) >> 16;
-            alive = shade_path<NEED_UV>(sc, prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
+            alive = shade_path<NEED_UV, HAS_MIX>(sc, prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
                                         f2u(o4.w) >> 24, f2u(d4.w) & 0xFFFFu, s_local, slot - s_local * P.npix, best);
         }
         compact_survivors(alive, slot, lane, &s_out, queue_out, c.seg);
@@ -715,7 +753,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, 
             }
             uint32_t c0 = 0, c1 = 0, c2 = 0;
             Closest best = traverse<false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-            alive = shade_path<NEED_UV>(sc, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
+            alive = shade_path<NEED_UV, false>(sc, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
         }
         compact_survivors(alive, slot, lane, &s_out, queue_out, c.seg);
     }
@@ -828,12 +866,14 @@ void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float
 }
 
 void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv) {
+                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv, bool has_mix) {
     dim3 g(grid), b(kBlock);
-    if (need_uv)
-        hipLaunchKernelGGL((k_shade<true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+    if (has_mix)
+        hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+    else if (need_uv)
+        hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
     else
-        hipLaunchKernelGGL((k_shade<false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+        hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
 }
 
 template <bool FIRST>

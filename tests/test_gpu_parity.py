@@ -17,7 +17,7 @@ from raytracer_amd import RenderSettings, SceneDescription, Sphere, _ffi as F
 from raytracer_amd.renderer import Context, Renderer, Scene, camera_from_settings
 from raytracer_amd.scene import Material, Texture, TriangleMesh
 from raytracer_amd.scenes import cornell_with, lit_teapot, rtiow_final_scene, triangle_soup
-from test_oracle import check_against_kat, check_bvh_structure, load_kat
+from test_oracle import check_against_kat, check_bvh_structure, load_kat, mix_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -251,6 +251,27 @@ def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
             render_pair(ctx, teapot, teapot.camera(0), RenderSettings(16, 16, 0, 4, 1))
         assert e.value.code == F.RT_ERR_INVALID_ARGUMENT and "LDS" in e.value.message
     ctx.close()
+
+
+def test_mix_materials(gpu_ctx, cornell):
+    """Mix (src/material.rs:186-204): blended attenuation, one extra draw to pick the ray, children that do
+    not scatter (a light), the factor 0 / 1 shortcuts and nesting four deep."""
+    def build(sc):
+        lam = sc.lambertian((0.7, 0.6, 0.5))
+        met = sc.metal((0.9, 0.85, 0.8), 0.3)
+        die = sc.dielectric(1.5)
+        light = sc.diffuse_light((1.0, 0.9, 0.8), 3.0)
+        nested = sc.mix(sc.mix(sc.mix(sc.mix(lam, met, 0.5), die, 0.25), light, 0.6), met, 0.7)
+        room = sc.mix(sc.mix(lam, light, 0.5), sc.mix(die, met, 1.0), 0.35)
+        return nested, room
+
+    desc = mix_scene(cornell, build)
+    for mode in (F.RT_MODE_LINEAR_MEAN, F.RT_MODE_GAMMA_PER_SAMPLE):
+        rs = RenderSettings(140, 100, 0, 50, 6, mode=mode, seed=21, background_color=(0.05, 0.1, 0.2))
+        gpu, cpu, gst, cst = render_pair(gpu_ctx, desc, desc.camera(0), rs)
+        assert_images_equal(gpu, cpu)
+        assert gst.rays_traced == cst.rays_traced
+        assert gst.pipeline in (F.RT_PIPELINE_SPLIT, F.RT_PIPELINE_SPLIT_LDS)
 
 
 def test_teapot_default_camera_is_black_and_lit_variant_matches(gpu_ctx, teapot):

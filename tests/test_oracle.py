@@ -298,3 +298,39 @@ def test_procedural_scenes_are_reproducible():
     assert s1.num_primitives == 5000 and len(s1.meshes) == 2
     o = ob.OracleScene(s1)
     assert o.info().num_nodes == 9999
+
+
+def mix_scene(cornell, build):
+    """Cornell with the big box (mesh 4) and the back/floor/ceiling mesh (mesh 0) given materials from `build`."""
+    sc = SceneDescription(list(cornell.meshes), [], list(cornell.materials), list(cornell.textures), list(cornell.cameras))
+    m_box, m_room = build(sc)
+    for idx, m in ((4, m_box), (0, m_room)):
+        b = sc.meshes[idx]
+        sc.meshes[idx] = TriangleMesh(b.positions, b.indices, b.normals, b.uvs, m)
+    return sc
+
+
+def test_mix_material_semantics(cornell):
+    """Mix::scatter (src/material.rs:186-204): factor 1 -> right alone, factor 0 -> left alone (bit-identical
+    images to using that material directly); other factors scatter both children and draw once more."""
+    cam = ob.camera_from_settings(cornell.camera(0), 48, 48)
+    rs = RenderSettings(48, 48, 0, 50, 4, mode=F.RT_MODE_LINEAR_MEAN, seed=12, background_color=(0.3, 0.3, 0.3))
+
+    def render(build):
+        img, st = ob.OracleScene(mix_scene(cornell, build)).render(cam, rs, threads=4)
+        return img, st
+
+    plain, _ = render(lambda sc: (sc.metal((0.9, 0.8, 0.7), 0.2), sc.lambertian((0.5, 0.6, 0.7))))
+    right, _ = render(lambda sc: (sc.mix(sc.dielectric(1.5), sc.metal((0.9, 0.8, 0.7), 0.2), 1.0),
+                                  sc.mix(sc.lambertian((0.5, 0.6, 0.7)), sc.dielectric(1.3), 0.0)))
+    assert bits_equal(plain, right).all()
+    both, st = render(lambda sc: (sc.mix(sc.dielectric(1.5), sc.metal((0.9, 0.8, 0.7), 0.2), 0.4),
+                                  sc.lambertian((0.5, 0.6, 0.7))))
+    assert not bits_equal(plain, both).all() and st.rays_traced > st.paths
+    with pytest.raises(F.RtError):  # nesting deeper than 4
+        def deep(sc):
+            m = sc.lambertian((0.5, 0.5, 0.5))
+            for _ in range(5):
+                m = sc.mix(m, sc.dielectric(1.5), 0.5)
+            return m, m
+        render(deep)
