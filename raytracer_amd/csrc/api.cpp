@@ -91,6 +91,7 @@ struct rt_context {
     DevBuf<float4> ray_o, ray_d, hit, beta, radiance;
     DevBuf<uint32_t> queue[2];
     DevBuf<uint32_t> counts;              // [max_depth + 1][grid] survivors per block and bounce
+    DevBuf<uint32_t> early;               // [max_depth + 1][grid] early misses per block and bounce
     DevBuf<unsigned long long> totals;    // [max_depth + 1] per-bounce sums of `counts`
     DevBuf<rt::ExtendCounters> counters;
     DevBuf<float> accum;     // rt_render's device image
@@ -137,6 +138,7 @@ int ensure_render(rt_context *c, size_t n, size_t queue_len, uint32_t max_depth,
     if (int rc = c->queue[0].ensure(queue_len)) return rc;
     if (int rc = c->queue[1].ensure(queue_len)) return rc;
     if (int rc = c->counts.ensure(((size_t)max_depth + 1) * grid)) return rc;
+    if (int rc = c->early.ensure(((size_t)max_depth + 1) * grid)) return rc;
     if (int rc = c->totals.ensure((size_t)max_depth + 1)) return rc;
     if (int rc = c->counters.ensure(1)) return rc;
     return RT_OK;
@@ -271,6 +273,7 @@ RT_API int rt_context_destroy(rt_context *c) {
     c->queue[0].release();
     c->queue[1].release();
     c->counts.release();
+    c->early.release();
     c->totals.release();
     c->counters.release();
     c->accum.release();
@@ -614,10 +617,11 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
             uint32_t *q_out = c->queue[it & 1].ptr;
             uint32_t *counts_out = c->counts.ptr + (size_t)(it + 1) * grid;
+            uint32_t *early_out = c->early.ptr + (size_t)(it + 1) * grid;
             const bool timed = it < c->timed_bounces;
             if (fused_all || (fused_first && it == 0)) {
                 if (int rc = timed_begin(c, it == 0 ? K_BOUNCE0 : K_BOUNCE, timed)) return rc;
-                rt::launch_bounce(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, it == 0, s->need_uv, lds_bytes);
+                rt::launch_bounce(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, early_out, it == 0, s->need_uv, lds_bytes);
                 if (int rc = timed_end(c, timed)) return rc;
                 ++bounce_launches;
             } else {
@@ -626,7 +630,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
                                   count ? c->counters.ptr : nullptr, lds_bytes);
                 if (int rc = timed_end(c, timed)) return rc;
                 if (int rc = timed_begin(c, K_SHADE, timed)) return rc;
-                rt::launch_shade(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, s->need_uv, s->has_mix);
+                rt::launch_shade(c->stream, grid, s->dev, P, ps, q, q_out, counts_out, early_out, s->need_uv, s->has_mix);
                 if (int rc = timed_end(c, timed)) return rc;
                 ++extend_launches;
                 ++shade_launches;
@@ -637,7 +641,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         rt::launch_accumulate(c->stream, c->max_blocks, P, ps.radiance, d_accum);
         if (int rc = timed_end(c)) return rc;
         if (stats && st->max_depth > 1) {
-            rt::launch_sum_counts(c->stream, c->counts.ptr + grid, grid, st->max_depth - 1, c->totals.ptr + 1);
+            rt::launch_sum_counts(c->stream, c->counts.ptr + grid, c->early.ptr + grid, grid, st->max_depth - 1, c->totals.ptr + 1);
             HIP_TRY(hipMemcpyAsync(c->host_counts + counts_len * bi, c->totals.ptr,
                                    counts_len * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         }

@@ -18,21 +18,23 @@ void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float
                    float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters,
                    uint32_t lds_bytes);
 
-// Shades the items of `q`; block b appends its surviving slots at queue_out[b * q.cap ...] and stores their
-// number in counts_out[b].
+// Shades the items of `q`; block b appends its surviving slots at queue_out[b * q.cap ...], stores their
+// number in counts_out[b] and in early_out[b] the number of paths it ended because their next ray misses the
+// scene's root box (those rays count as traced in the next bounce).
 // `has_mix` selects the variant that evaluates Mix materials (only the split kernels carry that code).
 void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv, bool has_mix);
+                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, uint32_t *early_out, bool need_uv,
+                  bool has_mix);
 
 // One whole path segment per item: camera ray generation (`first`), closest hit, shading, compaction.
 // `lds_bytes` != 0 stages the node and primitive tables in that many bytes of LDS (2 * 16 * n_nodes +
 // 3 * 16 * n_prims); the caller decides whether they fit.
 void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool first, bool need_uv,
-                   uint32_t lds_bytes);
+                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, uint32_t *early_out, bool first,
+                   bool need_uv, uint32_t lds_bytes);
 
-// totals[r] = sum of counts[r * n_blocks .. (r + 1) * n_blocks) for r in [0, n_rows).
-void launch_sum_counts(hipStream_t s, const uint32_t *counts, uint32_t n_blocks, uint32_t n_rows,
+// totals[r] = sum over b of counts[r * n_blocks + b] + early[r * n_blocks + b] for r in [0, n_rows).
+void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals);
 
 void launch_accumulate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const float4 *radiance, float *accum);

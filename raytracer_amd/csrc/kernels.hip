@@ -621,12 +621,20 @@ __global__ __launch_bounds__(kBlock) void k_extend_world(SceneDev sc, const floa
 // shading: the body of Renderer::ray_color's loop after `world.hit` (src/renderer.rs:46-66) for one path.
 // Writes the path's next state (and returns true) or its final radiance (and returns false).
 // ------------------------------------------------------------------------------------------------------
+//
+// Early miss: when the scattered ray does not even enter the scene's root box (a fifth of Cornell's diffuse
+// bounces leave the box at once), the next `world.hit` is known to return None: the path would come back next
+// bounce only to be assigned the background colour.  That assignment is done here instead and the function
+// returns kPathEndedByEarlyMiss so the caller can still count the ray; the sums are unchanged.
+enum : int { kPathEnded = 0, kPathAlive = 1, kPathEndedByEarlyMiss = 2 };
+
 template <bool NEED_UV, bool HAS_MIX>
-__device__ __forceinline__ bool shade_path(const SceneDev &sc, const float4 *__restrict__ prims, const RenderParams &P,
-                                           const PathState &st, uint32_t slot, V3 o, V3 d, V3 beta, uint32_t k,
-                                           uint32_t flags, uint32_t depth, uint32_t s_local, uint32_t pixel,
-                                           const Closest &best) {
+__device__ __forceinline__ int shade_path(const SceneDev &sc, const float4 *__restrict__ nodes,
+                                          const float4 *__restrict__ prims, const RenderParams &P, const PathState &st,
+                                          uint32_t slot, V3 o, V3 d, V3 beta, uint32_t k, uint32_t flags, uint32_t depth,
+                                          uint32_t s_local, uint32_t pixel, const Closest &best) {
     bool alive = false;
+    bool early_miss = false;
     const float qnan = __builtin_nanf("");
     V3 l = V3{(flags & 1u) ? qnan : 0.0f, (flags & 2u) ? qnan : 0.0f, (flags & 4u) ? qnan : 0.0f};
     if (best.slot == kMissSlot) {
@@ -650,6 +658,15 @@ __device__ __forceinline__ bool shade_path(const SceneDev &sc, const float4 *__r
             // src/renderer.rs:39-41: `while beta != 0` then `depth >= max_depth`
             alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
             if (alive) {
+                V3 nd = sr.direction;
+                V3 ninv = V3{1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z};
+                if (!box_hit(nodes[0], nodes[1], s.point, ninv, P.z_near, P.z_far)) {
+                    alive = false;
+                    early_miss = true;
+                    l = ld3(P.background);
+                }
+            }
+            if (alive) {
                 // a scattering material emits nothing, so l is still +0 or NaN per channel here
                 flags = (l.x != l.x ? 1u : 0u) | (l.y != l.y ? 2u : 0u) | (l.z != l.z ? 4u : 0u);
                 st.ray_o[slot] = mk4(s.point, u2f((rng.k & 0xFFFFFFu) | (flags << 24)));
@@ -659,13 +676,16 @@ __device__ __forceinline__ bool shade_path(const SceneDev &sc, const float4 *__r
         }
     }
     if (!alive) st.radiance[slot] = mk4(l, 0.0f);
-    return alive;
+    return alive ? kPathAlive : (early_miss ? kPathEndedByEarlyMiss : kPathEnded);
 }
 
 // Appends the surviving lanes' slots to the block's output segment: ranks from ballot + popcount, one LDS
 // atomic per wave.  Must be reached by all 64 lanes of the wave.
-__device__ __forceinline__ void compact_survivors(bool alive, uint32_t slot, uint32_t lane, uint32_t *s_out,
-                                                  uint32_t *__restrict__ queue_out, uint32_t seg) {
+__device__ __forceinline__ void compact_survivors(int outcome, uint32_t slot, uint32_t lane, uint32_t *s_out,
+                                                  uint32_t *s_early, uint32_t *__restrict__ queue_out, uint32_t seg) {
+    const bool alive = outcome == kPathAlive;
+    unsigned long long early = __ballot(outcome == kPathEndedByEarlyMiss);
+    if (early && lane == 0) atomicAdd(s_early, (uint32_t)__popcll(early));
     unsigned long long mask = __ballot(alive);
     if (mask) {
         uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
@@ -680,17 +700,22 @@ __device__ __forceinline__ void compact_survivors(bool alive, uint32_t slot, uin
 // shade: every queued path whose hit record extend has written.
 template <bool NEED_UV, bool HAS_MIX>
 __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, PathState st, QueueView q,
-                                                  uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out) {
-    __shared__ uint32_t s_out;
-    if (threadIdx.x == 0) s_out = 0u;
+                                                  uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out,
+                                                  uint32_t *__restrict__ early_out) {
+    __shared__ uint32_t s_out, s_early;
+    if (threadIdx.x == 0) {
+        s_out = 0u;
+        s_early = 0u;
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     QueueCursor c = queue_begin(q);
     // Whole waves iterate together so that the ballot in compact_survivors always sees all 64 lanes.
     for (uint32_t off = c.off; off < c.limit; off += c.stride) {
         const uint32_t i = off + threadIdx.x;
-        bool alive = false;
+        int alive = kPathEnded;
         uint32_t slot = 0;
         if (i < c.limit) {
             slot = c.ident ? i : q.items[c.seg + i];
@@ -700,13 +725,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
             float4 b4 = st.beta[slot];
             Closest best{h.x, f2u(h.y), h.z, h.w};
             const uint32_t s_local = f2u(d4.w) >> 16;
-            alive = shade_path<NEED_UV, HAS_MIX>(sc, prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
+            alive = shade_path<NEED_UV, HAS_MIX>(sc, nodes, prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
                                         f2u(o4.w) >> 24, f2u(d4.w) & 0xFFFFu, s_local, slot - s_local * P.npix, best);
         }
-        compact_survivors(alive, slot, lane, &s_out, queue_out, c.seg);
+        compact_survivors(alive, slot, lane, &s_out, &s_early, queue_out, c.seg);
     }
     __syncthreads();
-    if (threadIdx.x == 0) counts_out[blockIdx.x] = s_out;
+    if (threadIdx.x == 0) {
+        counts_out[blockIdx.x] = s_out;
+        early_out[blockIdx.x] = s_early;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -716,19 +744,23 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
 // ------------------------------------------------------------------------------------------------------
 template <bool FIRST, bool LDS_SCENE, bool NEED_UV>
 __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
-                                                   uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out) {
+                                                   uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out,
+                                                   uint32_t *__restrict__ early_out) {
     extern __shared__ float4 s_scene[];
-    __shared__ uint32_t s_out;
+    __shared__ uint32_t s_out, s_early;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
-    if (threadIdx.x == 0) s_out = 0u;
+    if (threadIdx.x == 0) {
+        s_out = 0u;
+        s_early = 0u;
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     QueueCursor c = queue_begin(q);
     for (uint32_t off = c.off; off < c.limit; off += c.stride) {
         const uint32_t i = off + threadIdx.x;
-        bool alive = false;
+        int alive = kPathEnded;
         uint32_t slot = 0;
         if (i < c.limit) {
             V3 o, d, beta;
@@ -753,22 +785,28 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, 
             }
             uint32_t c0 = 0, c1 = 0, c2 = 0;
             Closest best = traverse<false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-            alive = shade_path<NEED_UV, false>(sc, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
+            alive = shade_path<NEED_UV, false>(sc, nodes, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
         }
-        compact_survivors(alive, slot, lane, &s_out, queue_out, c.seg);
+        compact_survivors(alive, slot, lane, &s_out, &s_early, queue_out, c.seg);
     }
     __syncthreads();
-    if (threadIdx.x == 0) counts_out[blockIdx.x] = s_out;
+    if (threadIdx.x == 0) {
+        counts_out[blockIdx.x] = s_out;
+        early_out[blockIdx.x] = s_early;
+    }
 }
 
-// Per-bounce ray totals of a batch: totals[it] = sum over blocks of counts[it * n_blocks + b].
-__global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ counts, uint32_t n_blocks,
+// Per-bounce ray totals of a batch: totals[it] = sum over blocks of counts[it][b] + early[it][b] (queued rays
+// plus rays whose miss was settled a bounce early).
+__global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ counts,
+                                                       const uint32_t *__restrict__ early, uint32_t n_blocks,
                                                        unsigned long long *__restrict__ totals) {
     __shared__ unsigned long long s_sum;
     if (threadIdx.x == 0) s_sum = 0ull;
     __syncthreads();
     unsigned long long acc = 0;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += kBlock) acc += counts[(size_t)blockIdx.x * n_blocks + b];
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += kBlock)
+        acc += (unsigned long long)counts[(size_t)blockIdx.x * n_blocks + b] + early[(size_t)blockIdx.x * n_blocks + b];
     atomicAdd(&s_sum, acc);
     __syncthreads();
     if (threadIdx.x == 0) totals[blockIdx.x] = s_sum;
@@ -866,46 +904,47 @@ void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float
 }
 
 void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv, bool has_mix) {
+                  const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, uint32_t *early_out, bool need_uv,
+                  bool has_mix) {
     dim3 g(grid), b(kBlock);
     if (has_mix)
-        hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+        hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out);
     else if (need_uv)
-        hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+        hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out);
     else
-        hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+        hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out);
 }
 
 template <bool FIRST>
 static void launch_bounce_t(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                            const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool need_uv,
-                            uint32_t lds_bytes) {
+                            const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, uint32_t *early_out,
+                            bool need_uv, uint32_t lds_bytes) {
     dim3 g(grid), b(kBlock);
     if (lds_bytes) {
         if (need_uv)
-            hipLaunchKernelGGL((k_bounce<FIRST, true, true>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, true, true>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out);
         else
-            hipLaunchKernelGGL((k_bounce<FIRST, true, false>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, true, false>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out);
     } else {
         if (need_uv)
-            hipLaunchKernelGGL((k_bounce<FIRST, false, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, false, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out);
         else
-            hipLaunchKernelGGL((k_bounce<FIRST, false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out);
     }
 }
 
 void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, bool first, bool need_uv,
-                   uint32_t lds_bytes) {
+                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, uint32_t *early_out, bool first,
+                   bool need_uv, uint32_t lds_bytes) {
     if (first)
-        launch_bounce_t<true>(s, grid, sc, P, st, q, queue_out, counts_out, need_uv, lds_bytes);
+        launch_bounce_t<true>(s, grid, sc, P, st, q, queue_out, counts_out, early_out, need_uv, lds_bytes);
     else
-        launch_bounce_t<false>(s, grid, sc, P, st, q, queue_out, counts_out, need_uv, lds_bytes);
+        launch_bounce_t<false>(s, grid, sc, P, st, q, queue_out, counts_out, early_out, need_uv, lds_bytes);
 }
 
-void launch_sum_counts(hipStream_t s, const uint32_t *counts, uint32_t n_blocks, uint32_t n_rows,
+void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals) {
-    hipLaunchKernelGGL(k_sum_counts, dim3(n_rows), dim3(kBlock), 0, s, counts, n_blocks, totals);
+    hipLaunchKernelGGL(k_sum_counts, dim3(n_rows), dim3(kBlock), 0, s, counts, early, n_blocks, totals);
 }
 
 void launch_accumulate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const float4 *radiance, float *accum) {
