@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-WIDTH, HEIGHT, MAX_DEPTH, SEED = 1920, 1080, 50, 1
+WIDTH, HEIGHT, MAX_DEPTH, SEED = 1920, 1080, 50, 1  # --width / --height override the size for rehearsals only
 SPP_PER_STEP = 64
 MAX_PATHS = 1 << 26          # path slots per batch: 32 samples of a 1080p frame
 TIMED_BOUNCES = 6            # extend launches bracketed by HIP events per batch (they carry > 98 % of the rays)
@@ -55,26 +55,37 @@ def cpu_baseline(desc, cam_settings, threads):
 
 
 def main():
+    global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo is for rehearsals")
+    ap.add_argument("--share-device0", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank renders on cuda:0 (use with --backend gloo)")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device0 else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    WIDTH, HEIGHT = args.width, args.height
 
     from raytracer_amd import RenderSettings, _ffi as F, load_from_gltf
     from raytracer_amd.distributed import sample_range
@@ -93,23 +104,37 @@ def main():
     spp = args.spp_per_step
 
     total = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
-    step_buf = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+    # Two step buffers: while step i's accumulator is being all-reduced (RCCL runs on its own stream), step i + 1
+    # already renders into the other one.
+    step_bufs = [torch.zeros(npix * 3, dtype=torch.float32, device=dev) for _ in range(2)]
+    pending = [None, None]
     acc = {"rays": 0, "paths": 0, "bounce_ms": 0.0, "extend_ms": 0.0, "timed_rays": 0, "timed_launches": 0,
            "gpu_ms": 0.0, "shade_ms": 0.0, "generate_ms": 0.0, "accumulate_ms": 0.0, "pipeline": 0,
            "first_ms": 0.0, "first_rays": 0, "first_launches": 0}
+
+    def retire(slot: int):
+        """Wait for the all-reduce of buffer `slot` (if any) and fold it into the running total."""
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+            total.add_(step_bufs[slot])
 
     def step(index: int, record: bool):
         # step `index` covers global samples [index * spp * world, (index + 1) * spp * world); rank's block:
         begin, count = sample_range(spp * world, world, rank)
         rs = RenderSettings(WIDTH, HEIGHT, 0, MAX_DEPTH, spp * world, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=SEED,
                             sample_begin=index * spp * world + begin, sample_count=count).to_c()
-        step_buf.zero_()
+        slot = index & 1
+        retire(slot)
+        buf = step_bufs[slot]
+        buf.zero_()
         st = F.rt_stats()
         F.check(lib, lib.rt_render_device(ctx.handle, scene.handle, C.byref(cam), C.byref(rs),
-                                          C.c_void_p(step_buf.data_ptr()), C.byref(st)))
+                                          C.c_void_p(buf.data_ptr()), C.byref(st)))
         if world > 1:
-            dist.all_reduce(step_buf, op=dist.ReduceOp.SUM)
-        total.add_(step_buf)
+            pending[slot] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            total.add_(buf)
         if record:
             acc["rays"] += st.rays_traced
             acc["paths"] += st.paths
@@ -130,6 +155,8 @@ def main():
         step(i, False)
 
     def fence():
+        retire(0)
+        retire(1)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -237,7 +264,7 @@ def main():
                         "peak as the contract asks; the kernel is VALU-issue bound (profiles/r01_pmc_summary_*.txt)",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(desc, desc.camera(0), threads=min(16, os.cpu_count() or 1))
         print(json.dumps(out))
     if world > 1:

@@ -468,3 +468,35 @@ def test_cpp_host_cli(cornell, tmp_path):
     assert r.returncode == 0 and open(out, "rb").read().startswith(b"P6\n16 12\n255\n")
     r = subprocess.run([cli, "/nonexistent.gltf"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "error" in r.stderr
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's multi-rank path (sample sharding, double-buffered asynchronous all-reduce, max-over-ranks
+    timing) rehearsed with two processes sharing the one GPU over gloo; the real thing runs one rank per GPU
+    over RCCL.  The two-rank image must equal the one-rank image up to float association."""
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--width", "320", "--height", "180", "--spp-per-step", "4"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--share-device0"] + common,
+                         capture_output=True, text=True, timeout=280, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=280, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["config"]["allreduce_floats_per_step"] == 320 * 180 * 3
+    assert j1["n_gpus"] == 1 and j1["value"] > 0 and j2["value"] > 0
+    # two ranks x 4 spp x 3 steps cover samples 0..23; one rank covers 0..11: different sample sets, so compare
+    # only statistics here (the bit-level sharding identity is tested in test_batching_and_sample_ranges...)
+    assert abs(j1["rays_per_path"] - j2["rays_per_path"]) < 0.02
+    assert abs(j1["image_check"]["finite_mean"] - j2["image_check"]["finite_mean"]) < 0.02
+    assert j1["roofline"]["frac"] > 0 and "cpu_baseline" not in j2
