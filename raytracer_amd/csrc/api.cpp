@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -242,7 +243,12 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
     if (!c) return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory");
     c->device = device;
     c->flags = flags;
-    c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
+    uint32_t blocks_per_cu = 8u;
+    if (const char *e = std::getenv("RT_BLOCKS_PER_CU")) { // tuning knob for experiments
+        long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 64) blocks_per_cu = (uint32_t)v;
+    }
+    c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * blocks_per_cu;
     if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
     } else {
