@@ -334,6 +334,29 @@ int rt_render(rt_context *ctx, const rt_scene *scene, const rt_camera *camera, c
 int rt_render_device(rt_context *ctx, const rt_scene *scene, const rt_camera *camera,
                      const rt_settings *settings, float *d_accum, rt_stats *stats);
 
+/* Sums the accumulators of a sample-sharded render across GPUs, in place: afterwards every `d_accum[i]`
+ * (device memory of `ctxs[i]`'s device, `count` floats) holds the element-wise sum over all `n_gpus` buffers.
+ * This is the one exchange step of `aggregate_image += sample` (src/renderer.rs:135-137) when the samples of a
+ * frame are split over the GPUs of one node by `rt_settings.sample_begin/sample_count`; the reference itself is
+ * single-process and has no counterpart.  One host process drives all devices: one context per device, all
+ * distinct.  The reduction is RCCL's all-reduce (float32, sum) enqueued on each context's stream, so it is
+ * ordered after the renders already enqueued there and asynchronous to the host (call
+ * `rt_context_synchronize` on each context before reading).  RCCL is loaded at the first call;
+ * RT_ERR_UNSUPPORTED if it cannot be.  Multi-process hosts (one process per GPU) use their own communicator
+ * instead, e.g. torch.distributed. */
+int rt_allreduce_sum(rt_context *const *ctxs, int n_gpus, float *const *d_accum, size_t count);
+
+/* `Renderer::render` / passes of `Renderer::render_progressive` (src/renderer.rs:72-156) over the GPUs of one
+ * node, driven by one host process: the samples [sample_begin, sample_begin + sample_count) are split into
+ * `n_gpus` contiguous blocks (the first `sample_count % n_gpus` GPUs take one more), GPU i renders its block
+ * of every pixel with `scenes[i]` (the same scene created on `ctxs[i]`) into a private accumulator, the
+ * accumulators are summed with `rt_allreduce_sum` and the result is copied into `accum` (host memory,
+ * 3 * width * height floats, overwritten; un-normalised sums as for `rt_render`).  The GPUs run concurrently.
+ * The random stream is keyed on the global sample index, so the set of samples does not depend on `n_gpus`;
+ * only the order of the final float additions does.  With `n_gpus` == 1 the result equals `rt_render`'s. */
+int rt_render_node(rt_context *const *ctxs, const rt_scene *const *scenes, int n_gpus, const rt_camera *camera,
+                   const rt_settings *settings, float *accum);
+
 /* ------------------------------------------------------------------------------------------------------ */
 /* glTF import (host only)                                                                                */
 /* ------------------------------------------------------------------------------------------------------ */

@@ -144,6 +144,9 @@ EXPORTS = {
     "rt_gltf_camera": (C.c_int, [_vp, C.c_uint32, C.POINTER(rt_camera_settings)]),
     "rt_render_device": (C.c_int, [_vp, _vp, C.POINTER(rt_camera), C.POINTER(rt_settings), _vp,
                                    C.POINTER(rt_stats)]),
+    "rt_allreduce_sum": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_size_t]),
+    "rt_render_node": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.c_int, C.POINTER(rt_camera),
+                                 C.POINTER(rt_settings), _vp]),
 }
 
 

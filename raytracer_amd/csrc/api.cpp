@@ -3,6 +3,8 @@
 // Host-side driver of the wavefront pipeline: it owns the HBM workspace, enqueues generate / extend / shade /
 // accumulate on the context's stream and never reads a queue length back while a batch is in flight.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -11,8 +13,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
@@ -716,5 +720,149 @@ RT_API int rt_render(rt_context *c, const rt_scene *s, const rt_camera *cam, con
     if (int rc = rt_render_device(c, s, cam, st, c->accum.ptr, stats)) return rc;
     HIP_TRY(hipMemcpyAsync(accum, c->accum.ptr, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// rt_allreduce_sum: RCCL all-reduce over the contexts of one process.  RCCL is bound with dlopen so that the
+// library (and single-GPU users) do not depend on it at load time.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string why;
+};
+
+// One communicator set per distinct device list, kept for the life of the process.
+struct CommSet {
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+};
+
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+std::vector<CommSet> g_comm_sets;
+
+bool load_rccl() {
+    if (g_rccl.handle) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) {
+        g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.handle) break;
+        g_rccl.why = dlerror();
+    }
+    if (!g_rccl.handle) return false;
+    bool ok = true;
+    auto bind = [&](auto &fn, const char *sym) {
+        fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(g_rccl.handle, sym));
+        if (!fn) {
+            ok = false;
+            g_rccl.why = std::string("missing symbol ") + sym;
+        }
+    };
+    bind(g_rccl.comm_init_all, "ncclCommInitAll");
+    bind(g_rccl.comm_destroy, "ncclCommDestroy");
+    bind(g_rccl.all_reduce, "ncclAllReduce");
+    bind(g_rccl.group_start, "ncclGroupStart");
+    bind(g_rccl.group_end, "ncclGroupEnd");
+    bind(g_rccl.error_string, "ncclGetErrorString");
+    if (!ok) {
+        dlclose(g_rccl.handle);
+        g_rccl.handle = nullptr;
+    }
+    return ok;
+}
+
+} // namespace
+
+RT_API int rt_allreduce_sum(rt_context *const *ctxs, int n_gpus, float *const *d_accum, size_t count) {
+    if (!ctxs || !d_accum || n_gpus <= 0) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_allreduce_sum: null argument or no GPUs");
+    std::vector<int> devices((size_t)n_gpus);
+    for (int i = 0; i < n_gpus; ++i) {
+        if (!ctxs[i] || (count && !d_accum[i])) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_allreduce_sum: null entry %d", i);
+        devices[(size_t)i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devices[(size_t)j] == devices[(size_t)i])
+                return set_error(RT_ERR_INVALID_ARGUMENT, "rt_allreduce_sum: contexts %d and %d share device %d", j, i, devices[(size_t)i]);
+    }
+    if (count == 0) return RT_OK;
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!load_rccl()) return set_error(RT_ERR_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());
+    CommSet *set = nullptr;
+    for (auto &s : g_comm_sets)
+        if (s.devices == devices) set = &s;
+    if (!set) {
+        CommSet s;
+        s.devices = devices;
+        s.comms.resize((size_t)n_gpus);
+        ncclResult_t r = g_rccl.comm_init_all(s.comms.data(), n_gpus, devices.data());
+        if (r != ncclSuccess) return set_error(RT_ERR_DEVICE, "ncclCommInitAll: %s", g_rccl.error_string(r));
+        g_comm_sets.push_back(std::move(s));
+        set = &g_comm_sets.back();
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    ncclResult_t r = g_rccl.group_start();
+    for (int i = 0; i < n_gpus && r == ncclSuccess; ++i) {
+        if (hipSetDevice(devices[(size_t)i]) != hipSuccess) {
+            (void)g_rccl.group_end();
+            if (prev >= 0) (void)hipSetDevice(prev);
+            return set_error(RT_ERR_DEVICE, "hipSetDevice(%d) failed", devices[(size_t)i]);
+        }
+        r = g_rccl.all_reduce(d_accum[i], d_accum[i], count, ncclFloat, ncclSum, set->comms[(size_t)i], ctxs[i]->stream);
+    }
+    ncclResult_t e = g_rccl.group_end();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) return set_error(RT_ERR_DEVICE, "ncclAllReduce: %s", g_rccl.error_string(r));
+    return RT_OK;
+}
+
+RT_API int rt_render_node(rt_context *const *ctxs, const rt_scene *const *scenes, int n_gpus, const rt_camera *cam,
+                          const rt_settings *st, float *accum) {
+    if (!ctxs || !scenes || !cam || !st || !accum || n_gpus <= 0)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render_node: null argument or no GPUs");
+    if (st->image_width == 0 || st->image_height == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "image size must be non-zero");
+    for (int i = 0; i < n_gpus; ++i) {
+        if (!ctxs[i] || !scenes[i]) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render_node: null entry %d", i);
+        if (scenes[i]->device != ctxs[i]->device)
+            return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render_node: scene %d lives on device %d, its context on device %d", i,
+                             scenes[i]->device, ctxs[i]->device);
+    }
+    const size_t n = (size_t)st->image_width * st->image_height * 3;
+    const uint32_t total = st->sample_count ? st->sample_count : st->samples_per_pixel;
+    const uint32_t base = total / (uint32_t)n_gpus, extra = total % (uint32_t)n_gpus;
+    std::vector<float *> bufs((size_t)n_gpus);
+    uint32_t begin = st->sample_begin;
+    for (int i = 0; i < n_gpus; ++i) { // enqueue every GPU's share; nothing here waits for a device
+        rt_context *c = ctxs[i];
+        DeviceGuard guard(c->device);
+        if (!guard.ok) return set_error(RT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+        if (int rc = c->accum.ensure(n)) return rc;
+        bufs[(size_t)i] = c->accum.ptr;
+        HIP_TRY(hipMemsetAsync(c->accum.ptr, 0, n * sizeof(float), c->stream));
+        rt_settings part = *st;
+        part.sample_begin = begin;
+        part.sample_count = base + ((uint32_t)i < extra ? 1u : 0u);
+        begin += part.sample_count;
+        if (part.sample_count == 0) continue; // more GPUs than samples: this one contributes zeros
+        if (int rc = rt_render_device(c, scenes[i], cam, &part, c->accum.ptr, nullptr)) return rc;
+    }
+    if (n_gpus > 1)
+        if (int rc = rt_allreduce_sum(ctxs, n_gpus, bufs.data(), n)) return rc;
+    {
+        rt_context *c = ctxs[0];
+        DeviceGuard guard(c->device);
+        HIP_TRY(hipMemcpyAsync(accum, c->accum.ptr, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    for (int i = 0; i < n_gpus; ++i)
+        if (int rc = rt_context_synchronize(ctxs[i])) return rc;
     return RT_OK;
 }

@@ -1,9 +1,10 @@
 // rt_cli — command-line driver with the reference CLI's flags (src/main.rs:38-65):
 //   rt_cli [--bvh-disabled] [--debug] [-W|--width N] [-H|--height N] [-d|--max-depth N] [--spp N]
-//          [-c|--camera N] [--seed N] [--batch] [--device N] INPUT.gltf [OUTPUT.(ppm|pfm)]
+//          [-c|--camera N] [--seed N] [--batch] [--device N] [--gpus N] INPUT.gltf [OUTPUT.(ppm|pfm)]
 // Like `main` it loads the glTF file, builds the BVH, picks the camera and renders progressively
 // (src/main.rs:91-104); instead of streaming to a tev viewer it writes the last report to OUTPUT.  `--batch`
 // runs `Renderer::render` (linear mean) instead.  `--bvh-disabled` is accepted and ignored, as in the reference.
+// `--gpus N` splits every pass's samples over devices 0..N-1 of the node (one all-reduce per pass).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +17,7 @@ int main(int argc, char **argv) {
     using namespace rt::host;
     RenderSettings rs;
     bool debug = false, batch = false;
-    int device = 0;
+    int device = 0, gpus = 0;
     std::string input, output = "image.ppm";
     int positional = 0;
     auto need = [&](int &i) -> const char * {
@@ -38,9 +39,10 @@ int main(int argc, char **argv) {
         else if (a == "-c" || a == "--camera") rs.selected_camera = std::strtoul(need(i), nullptr, 10);
         else if (a == "--seed") rs.seed = std::strtoull(need(i), nullptr, 10);
         else if (a == "--device") device = std::atoi(need(i));
+        else if (a == "--gpus") gpus = std::atoi(need(i));
         else if (a == "-h" || a == "--help") {
             std::printf("usage: rt_cli [--bvh-disabled] [--debug] [-W N] [-H N] [-d N] [--spp N] [-c N] [--seed N] [--batch] "
-                        "[--device N] INPUT.gltf [OUTPUT.ppm|OUTPUT.pfm]\n");
+                        "[--device N] [--gpus N] INPUT.gltf [OUTPUT.ppm|OUTPUT.pfm]\n");
             return 0;
         } else if (!a.empty() && a[0] == '-') {
             std::fprintf(stderr, "unknown flag %s\n", a.c_str());
@@ -55,10 +57,29 @@ int main(int argc, char **argv) {
     try {
         using clock = std::chrono::steady_clock;
         auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        Context ctx(device);
         auto t0 = clock::now();
         SceneDescription desc = SceneDescription::load_from_gltf(input);
         auto t1 = clock::now();
+        if (gpus > 0) { // one process, several GPUs
+            rt_camera camera = make_camera(desc.camera(rs.selected_camera), rs.image_width, rs.image_height);
+            NodeRenderer renderer(gpus, desc.desc(), camera, rs);
+            auto t2 = clock::now();
+            std::printf("loaded %s in %.1f ms; building the BVH on %d GPUs took %.1f ms\n", input.c_str(), ms(t0, t1), gpus, ms(t1, t2));
+            ImageOutput out{output};
+            if (batch) {
+                out.write(renderer.render(16), rs.image_width, rs.image_height);
+            } else {
+                std::vector<float> last;
+                renderer.render_progressive([&](const std::vector<float> &px, uint32_t, uint32_t, uint32_t sample) {
+                    if (debug) std::printf("Outputted image after sample %u\n", sample);
+                    last = px;
+                });
+                out.write(last, rs.image_width, rs.image_height);
+            }
+            std::printf("Rendering took %.1f ms on %d GPUs; wrote %s\n", ms(t2, clock::now()), gpus, output.c_str());
+            return 0;
+        }
+        Context ctx(device);
         Scene scene(ctx, desc.desc());
         auto t2 = clock::now();
         rt_scene_info info = scene.info();

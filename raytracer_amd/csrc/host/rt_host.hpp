@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -213,6 +214,70 @@ class Renderer {
     const Context &ctx_;
     rt_camera camera_;
     const Scene &scene_;
+    RenderSettings render_;
+};
+
+// The same renderer over several GPUs of one node, driven by this one process: the scene is replicated on
+// devices 0 .. n_gpus-1, every pass splits its samples over the GPUs (`rt_render_node`) and one RCCL
+// all-reduce adds the accumulators.  Not in the reference, which is single-device.
+class NodeRenderer {
+  public:
+    NodeRenderer(int n_gpus, const rt_scene_desc *desc, rt_camera camera, RenderSettings render, uint32_t flags = 0)
+        : camera_(camera), render_(render) {
+        for (int d = 0; d < n_gpus; ++d) {
+            ctxs_.push_back(std::make_unique<Context>(d, flags));
+            scenes_.push_back(std::make_unique<Scene>(*ctxs_.back(), desc));
+            raw_ctxs_.push_back(ctxs_.back()->get());
+            raw_scenes_.push_back(scenes_.back()->get());
+        }
+    }
+
+    std::vector<float> render(size_t /*square_size*/ = 16) const {
+        std::vector<float> sums = pass(RT_MODE_LINEAR_MEAN, 0, render_.samples_per_pixel);
+        const float sample_scale = 1.0f / (float)render_.samples_per_pixel;
+        for (float &c : sums) c = c * sample_scale;
+        return sums;
+    }
+
+    void render_progressive(const std::function<void(const std::vector<float> &, uint32_t, uint32_t, uint32_t)> &output,
+                            size_t /*square_size*/ = 16) const {
+        const uint32_t w = render_.image_width, h = render_.image_height, spp = render_.samples_per_pixel;
+        std::vector<float> aggregate((size_t)w * h * 3, 0.0f);
+        uint32_t done = 0;
+        while (done < spp) {
+            uint32_t next = done + 1;
+            while (!should_save_image(next, spp)) ++next;
+            std::vector<float> part = pass(RT_MODE_GAMMA_PER_SAMPLE, done, next - done);
+            for (size_t i = 0; i < aggregate.size(); ++i) aggregate[i] += part[i];
+            done = next;
+            const float sample_scale = 1.0f / (float)done;
+            std::vector<float> image(aggregate.size());
+            for (size_t i = 0; i < aggregate.size(); ++i) image[i] = aggregate[i] * sample_scale;
+            output(image, w, h, done);
+        }
+    }
+
+  private:
+    std::vector<float> pass(uint32_t mode, uint32_t begin, uint32_t count) const {
+        rt_settings st{};
+        st.image_width = render_.image_width;
+        st.image_height = render_.image_height;
+        st.max_depth = render_.max_depth;
+        st.samples_per_pixel = render_.samples_per_pixel;
+        for (int i = 0; i < 3; ++i) st.background_color[i] = render_.background_color[i];
+        st.mode = mode;
+        st.seed = render_.seed;
+        st.sample_begin = begin;
+        st.sample_count = count;
+        std::vector<float> sums((size_t)st.image_width * st.image_height * 3);
+        check(rt_render_node(raw_ctxs_.data(), raw_scenes_.data(), (int)raw_ctxs_.size(), &camera_, &st, sums.data()));
+        return sums;
+    }
+    std::vector<std::unique_ptr<Context>> ctxs_;
+    std::vector<std::unique_ptr<Scene>> scenes_;
+    std::vector<rt_context *> raw_ctxs_;
+    std::vector<const rt_scene *> raw_scenes_;
+    rt_camera camera_;
     RenderSettings render_;
 };
 

@@ -33,3 +33,41 @@ def render_sharded(render_range: Callable[[int, int, "object"], None], total_sam
 
         dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
     return accum
+
+
+def allreduce_sum(contexts, device_pointers, count: int) -> None:
+    """`rt_allreduce_sum`: one host process driving several GPUs (one `Context` each) sums their accumulators
+    (`device_pointers[i]` = address of `count` floats on `contexts[i]`'s device) in place with RCCL.  The
+    reduction is enqueued on every context's stream; synchronise the contexts before reading."""
+    import ctypes as C
+
+    from . import _ffi as F
+
+    lib = F.load_library()
+    n = len(contexts)
+    if n != len(device_pointers):
+        raise ValueError("one buffer per context")
+    ctxs = (C.c_void_p * n)(*[c.handle for c in contexts])
+    bufs = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in device_pointers])
+    F.check(lib, lib.rt_allreduce_sum(ctxs, n, bufs, count))
+
+
+def render_node(contexts, scenes, camera, settings):
+    """`rt_render_node`: one pass over the GPUs of a node from this process; `scenes[i]` is the scene created on
+    `contexts[i]`.  Returns the un-normalised sums, shape (H, W, 3)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _ffi as F
+
+    lib = F.load_library()
+    n = len(contexts)
+    if n != len(scenes):
+        raise ValueError("one scene per context")
+    st = settings.to_c() if hasattr(settings, "to_c") else settings
+    ctxs = (C.c_void_p * n)(*[c.handle for c in contexts])
+    scs = (C.c_void_p * n)(*[s.handle for s in scenes])
+    out = np.zeros((st.image_height, st.image_width, 3), dtype=np.float32)
+    F.check(lib, lib.rt_render_node(ctxs, scs, n, C.byref(camera), C.byref(st), out.ctypes.data))
+    return out

@@ -470,6 +470,51 @@ def test_cpp_host_cli(cornell, tmp_path):
     assert r.returncode == 1 and "error" in r.stderr
 
 
+def test_single_process_node_entry_points(gpu_ctx, cornell, tmp_path):
+    """rt_render_node / rt_allreduce_sum, the single-process multi-GPU entry points, on the one GPU this box
+    has: a one-GPU node render must equal rt_render bit for bit, an all-reduce over one buffer (RCCL bound
+    with dlopen) must leave it unchanged, and two contexts on one device are refused.  The N > 1 exchange is
+    RCCL's own all-reduce and cannot run here."""
+    import subprocess
+
+    import torch
+
+    from raytracer_amd.distributed import allreduce_sum, render_node
+
+    scene = Scene(gpu_ctx, cornell)
+    w, h, spp = 96, 64, 6
+    cam = camera_from_settings(cornell.camera(0), w, h)
+    for mode in (F.RT_MODE_LINEAR_MEAN, F.RT_MODE_GAMMA_PER_SAMPLE):
+        rs = RenderSettings(w, h, 0, 50, spp, mode=mode, seed=5)
+        want = Renderer(cam, scene, rs).render_sums()
+        assert bits_equal(render_node([gpu_ctx], [scene], cam, rs), want).all()
+        part = RenderSettings(w, h, 0, 50, spp, mode=mode, seed=5, sample_begin=2, sample_count=3)
+        assert bits_equal(render_node([gpu_ctx], [scene], cam, part), Renderer(cam, scene, part).render_sums()).all()
+    buf = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.25
+    keep = buf.clone()
+    allreduce_sum([gpu_ctx], [buf.data_ptr()], buf.numel())
+    gpu_ctx.synchronize()
+    assert torch.equal(buf, keep)
+    allreduce_sum([gpu_ctx], [0], 0)  # nothing to do
+    other = Context(0)
+    with pytest.raises(F.RtError) as e:
+        allreduce_sum([gpu_ctx, other], [buf.data_ptr(), keep.data_ptr()], buf.numel())
+    assert e.value.code == F.RT_ERR_INVALID_ARGUMENT and "share device" in e.value.message
+    with pytest.raises(F.RtError):
+        allreduce_sum([], [], 4)
+    # the C++ host's --gpus path (NodeRenderer) against its single-context path
+    cli = os.path.join(os.path.dirname(F.LIB_PATH), "rt_cli")
+    asset = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "cornell.gltf")
+    outs = []
+    for extra in ([], ["--gpus", "1"]):
+        out = str(tmp_path / f"node{len(outs)}.pfm")
+        r = subprocess.run([cli, "-W", "64", "-H", "48", "--spp", "5", "--seed", "3", "--batch", *extra, asset, out],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(_read_pfm(out))
+    assert bits_equal(outs[0], outs[1]).all()
+
+
 def test_bench_two_ranks_rehearsal(tmp_path):
     """bench.py's multi-rank path (sample sharding, double-buffered asynchronous all-reduce, max-over-ranks
     timing) rehearsed with two processes sharing the one GPU over gloo; the real thing runs one rank per GPU
