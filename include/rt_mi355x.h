@@ -365,8 +365,10 @@ int rt_render_node(rt_context *const *ctxs, const rt_scene *const *scenes, int n
  * way the reference's loader does — every node's LOCAL transform, the first TRIANGLES primitive of its mesh,
  * positions transformed and normals not, emissive materials as white DiffuseLight of the emissive strength and
  * everything else as Lambertian of the base colour factor, perspective cameras with focus distance 10.
- * Base-colour image textures are reported as RT_ERR_PARSE (no image decoder is linked).  The returned object
- * owns every buffer the scene description points into. */
+ * Base-colour textures (`load_image`, src/scene.rs:87-114) are decoded from PNG: 8-bit grey, grey+alpha, RGB,
+ * RGBA, palette and 1/2/4-bit grey, interlaced or not; 16-bit samples are refused as the reference refuses
+ * them, and JPEG files are refused because no JPEG decoder is linked (both RT_ERR_PARSE).  The returned
+ * object owns every buffer the scene description points into. */
 typedef struct rt_gltf rt_gltf;
 int rt_gltf_load(const char *path, rt_gltf **out);
 int rt_gltf_free(rt_gltf *gltf);

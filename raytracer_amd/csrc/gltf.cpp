@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
+#include "png_decode.h"
 
 namespace rt {
 void set_last_error(const std::string &message); // api.cpp: the message rt_last_error() returns
@@ -260,6 +261,26 @@ struct Document {
         }
     }
 
+    // The encoded file of image `index`: a data URI, a file next to the document, or a buffer view.
+    std::string image_bytes(size_t index) const {
+        const Json &img = root.at("images").at(index);
+        if (const Json *uri = img.find("uri")) {
+            const std::string &u = uri->str;
+            if (u.rfind("data:", 0) == 0) {
+                size_t comma = u.find(',');
+                if (comma == std::string::npos) throw std::runtime_error("bad data URI");
+                return base64_decode(u.data() + comma + 1, u.size() - comma - 1);
+            }
+            return read_file(dir + "/" + u);
+        }
+        const Json &bv = root.at("bufferViews").at(img.at("bufferView").index());
+        const std::string &buf = buffers.at(bv.at("buffer").index());
+        const size_t start = bv.has("byteOffset") ? bv.at("byteOffset").index() : 0;
+        const size_t len = bv.at("byteLength").index();
+        if (start + len > buf.size()) throw std::runtime_error("image buffer view exceeds its buffer");
+        return buf.substr(start, len);
+    }
+
     // Reads accessor `index` as rows of `want_comps` values converted by `conv(component_type, ptr)`.
     template <class T, class Conv> std::vector<T> read_accessor(size_t index, size_t want_comps, Conv conv) const {
         const Json &a = root.at("accessors").at(index);
@@ -345,6 +366,7 @@ struct rt_gltf {
     std::vector<rt_mesh> meshes;
     std::vector<rt_material> materials;
     std::vector<rt_texture> textures;
+    std::vector<std::vector<uint8_t>> texels; // decoded images the IMAGE textures point into
     std::vector<rt_camera_settings> cameras;
     rt_scene_desc desc{};
 };
@@ -358,6 +380,35 @@ int add_solid(rt_gltf &g, float r, float gr, float b) {
     t.rgb[1] = gr;
     t.rgb[2] = b;
     t.even = t.odd = -1;
+    g.textures.push_back(t);
+    return (int)g.textures.size() - 1;
+}
+
+// `load_image` (src/scene.rs:87-114) on the image the gltf crate decoded: PNG only here (no JPEG decoder).
+struct DecodedImage {
+    uint32_t width = 0, height = 0;
+    std::vector<uint8_t> rgb;
+};
+
+DecodedImage decode_image(const std::string &file) {
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(file.data());
+    if (file.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8)
+        throw std::runtime_error("JPEG base-colour textures are not supported (no JPEG decoder in this build); use PNG");
+    DecodedImage img;
+    std::string err;
+    if (!rt::decode_png_rgb8(bytes, file.size(), img.width, img.height, img.rgb, err))
+        throw std::runtime_error("base-colour texture: " + err);
+    return img;
+}
+
+int add_image(rt_gltf &g, DecodedImage &&img) {
+    g.texels.push_back(std::move(img.rgb));
+    rt_texture t{};
+    t.kind = RT_TEX_IMAGE;
+    t.even = t.odd = -1;
+    t.width = img.width;
+    t.height = img.height;
+    t.pixels = g.texels.back().data();
     g.textures.push_back(t);
     return (int)g.textures.size() - 1;
 }
@@ -389,6 +440,14 @@ void load_into(const std::string &path, rt_gltf &g) {
             if (const Json *e = mat.find("emissiveFactor")) for (int i = 0; i < 3; ++i) emissive[i] = (float)e->at(i).number();
             rt_material rm{};
             rm.left = rm.right = -1;
+            // The reference decodes the base-colour image before it looks at the emissive factor
+            // (src/scene.rs:138-149), so an undecodable image fails the load even on an emitter.
+            DecodedImage image;
+            const Json *bct = pbr.find("baseColorTexture");
+            if (bct) {
+                const Json &tex = root.at("textures").at(bct->at("index").index());
+                image = decode_image(doc.image_bytes(tex.at("source").index()));
+            }
             if (emissive[0] != 0.0f || emissive[1] != 0.0f || emissive[2] != 0.0f) {
                 float strength = 1.0f;
                 if (const Json *ext = mat.find("extensions"))
@@ -397,8 +456,9 @@ void load_into(const std::string &path, rt_gltf &g) {
                 rm.kind = RT_MAT_DIFFUSE_LIGHT;
                 rm.texture = add_solid(g, 1.0f, 1.0f, 1.0f);
                 rm.param = strength;
-            } else if (pbr.has("baseColorTexture")) {
-                throw std::runtime_error("base-colour image textures need an image decoder, which this build does not have");
+            } else if (bct) {
+                rm.kind = RT_MAT_LAMBERTIAN;
+                rm.texture = add_image(g, std::move(image));
             } else {
                 float col[3] = {1.0f, 1.0f, 1.0f};
                 if (const Json *c = pbr.find("baseColorFactor")) for (int i = 0; i < 3; ++i) col[i] = (float)c->at(i).number();

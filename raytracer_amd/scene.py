@@ -364,7 +364,10 @@ def load_from_gltf(path: str, image_decoder=None) -> SceneDescription:
     yields no faces; a non-zero emissive factor makes a white DiffuseLight of the material's emissive
     strength, anything else a Lambertian of the base colour.
 
-    `image_decoder(bytes) -> (H, W, 3) uint8` is needed only for base-colour textures."""
+    `image_decoder(bytes) -> (H, W, 3) uint8` decodes base-colour textures; the default reads PNG
+    (`raytracer_amd.png.decode_png_rgb8`)."""
+    if image_decoder is None:
+        from .png import decode_png_rgb8 as image_decoder
     g = _Gltf(path)
     doc = g.doc
     scene = SceneDescription()
@@ -379,15 +382,10 @@ def load_from_gltf(path: str, image_decoder=None) -> SceneDescription:
             mat = doc["materials"][prim["material"]] if "material" in prim else {}
             pbr = mat.get("pbrMetallicRoughness", {})
             emissive = [float(f32(c)) for c in mat.get("emissiveFactor", [0.0, 0.0, 0.0])]
-            if any(c != 0.0 for c in emissive):
-                strength = mat.get("extensions", {}).get("KHR_materials_emissive_strength", {}).get(
-                    "emissiveStrength", 1.0)
-                mid = scene.diffuse_light((1.0, 1.0, 1.0), strength)
-            elif "baseColorTexture" in pbr:
+            image = None
+            if "baseColorTexture" in pbr:  # decoded before the emissive test, as in src/scene.rs:138-149
                 tex = doc["textures"][pbr["baseColorTexture"]["index"]]
                 img = doc["images"][tex["source"]]
-                if image_decoder is None:
-                    raise NotImplementedError("base-colour textures need an image decoder")
                 if "uri" in img:
                     uri = img["uri"]
                     raw = base64.b64decode(uri.split(",", 1)[1]) if uri.startswith("data:") else open(
@@ -395,7 +393,13 @@ def load_from_gltf(path: str, image_decoder=None) -> SceneDescription:
                 else:
                     bv = doc["bufferViews"][img["bufferView"]]
                     raw = g.buffers[bv["buffer"]][bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
-                mid = scene.lambertian_texture(scene.add_texture(Texture.from_image(image_decoder(raw))))
+                image = image_decoder(bytes(raw))
+            if any(c != 0.0 for c in emissive):
+                strength = mat.get("extensions", {}).get("KHR_materials_emissive_strength", {}).get(
+                    "emissiveStrength", 1.0)
+                mid = scene.diffuse_light((1.0, 1.0, 1.0), strength)
+            elif image is not None:
+                mid = scene.lambertian_texture(scene.add_texture(Texture.from_image(image)))
             else:
                 col = pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])
                 mid = scene.lambertian(col[:3])
@@ -436,7 +440,12 @@ def load_from_gltf_native(path: str) -> SceneDescription:
         sc = SceneDescription()
         for i in range(d.num_textures):
             t = d.textures[i]
-            sc.textures.append(Texture(t.kind, (t.rgb[0], t.rgb[1], t.rgb[2]), t.inv_scale, t.even, t.odd))
+            tex = Texture(t.kind, (t.rgb[0], t.rgb[1], t.rgb[2]), t.inv_scale, t.even, t.odd)
+            if t.kind == F.RT_TEX_IMAGE:
+                n = int(t.width) * int(t.height) * 3
+                px = np.ctypeslib.as_array(t.pixels, shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+                tex.image = px.reshape(int(t.height), int(t.width), 3)
+            sc.textures.append(tex)
         for i in range(d.num_materials):
             m = d.materials[i]
             sc.materials.append(Material(m.kind, m.texture, m.param, m.left, m.right))

@@ -97,3 +97,63 @@ def brute_force_f64(desc, rays, t_min, t_max, rel_tie=1e-6):
         else:
             cands.append(set(np.nonzero(np.abs(t[i] - best[i]) <= rel_tie * max(1.0, abs(best[i])))[0].tolist()))
     return best, cands
+
+
+def encode_png(samples, ctype, depth=8, palette=None, interlace=False, filters=(0, 1, 2, 3, 4)):
+    """Minimal PNG writer for the decoder tests: `samples` is (H, W, channels) of sample values below
+    2**depth; rows cycle through the given filter types; `interlace` writes the seven Adam7 passes."""
+    import struct
+    import zlib
+
+    samples = np.asarray(samples)
+    h, w, ch = samples.shape
+    bpp = max(1, ch * depth // 8)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+    def rows_of(sub):
+        if depth == 8:
+            return sub.reshape(sub.shape[0], -1).astype(np.uint8)
+        if depth == 16:
+            return sub.astype(">u2").reshape(sub.shape[0], -1).view(np.uint8)
+        bits = ((sub[..., 0][..., None].astype(np.int64) >> np.arange(depth - 1, -1, -1)) & 1).astype(np.uint8)
+        return np.packbits(bits.reshape(sub.shape[0], -1), axis=1)
+
+    def filtered(rows, first_filter):
+        out = bytearray()
+        prev = np.zeros(rows.shape[1], dtype=np.int32)
+        for y, row in enumerate(rows.astype(np.int32)):
+            f = filters[(first_filter + y) % len(filters)]
+            left = np.concatenate([np.zeros(bpp, np.int32), row[:-bpp]]) if rows.shape[1] > bpp else np.zeros_like(row)
+            upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if rows.shape[1] > bpp else np.zeros_like(row)
+            if f == 0:
+                pred = np.zeros_like(row)
+            elif f == 1:
+                pred = left
+            elif f == 2:
+                pred = prev
+            elif f == 3:
+                pred = (left + prev) >> 1
+            else:
+                p = left + prev - upleft
+                pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out.append(f)
+            out += ((row - pred) & 0xFF).astype(np.uint8).tobytes()
+            prev = row
+        return bytes(out)
+
+    raw = b""
+    passes = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)) if interlace else ((0, 0, 1, 1),)
+    for k, (x0, y0, dx, dy) in enumerate(passes):
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] and sub.shape[1]:
+            raw += filtered(rows_of(sub), k)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        png += chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes())
+    data = zlib.compress(raw, 6)
+    half = len(data) // 2
+    png += chunk(b"tEXt", b"Comment\0two IDAT chunks follow") + chunk(b"IDAT", data[:half]) + chunk(b"IDAT", data[half:])
+    return png + chunk(b"IEND", b"")

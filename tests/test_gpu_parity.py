@@ -314,6 +314,34 @@ def test_image_texture(gpu_ctx, cornell):
     assert_images_equal(gpu, cpu)
 
 
+def test_png_textured_gltf_end_to_end(gpu_ctx, tmp_path):
+    """A glTF file whose base-colour texture is a PNG, read by the library's own reader (rt_gltf_load + its PNG
+    decoder) and rendered on the GPU, against the oracle fed by the Python reader: same sums bit for bit.  A
+    light quad is added on both sides so that the texture colour reaches the image."""
+    from helpers import encode_png
+    from raytracer_amd.scene import CameraSettings, load_from_gltf, load_from_gltf_native
+    from test_host import _textured_gltf
+
+    rng = np.random.default_rng(21)
+    png = encode_png(rng.integers(0, 256, (6, 11, 4)), 6, interlace=True)
+    path = _textured_gltf(tmp_path, "textured", png, "glb")
+    scenes = []
+    for sc in (load_from_gltf_native(path), load_from_gltf(path)):
+        light = sc.diffuse_light((1.0, 1.0, 1.0), 4.0)
+        pos = np.array([[-2, -2, 1.5], [3, -2, 1.5], [3, 3, 1.5], [-2, 3, 1.5]], dtype=np.float32)
+        sc.meshes.append(TriangleMesh(pos, np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32), np.zeros((0, 3), np.float32),
+                                      np.zeros((0, 2), np.float32), light))
+        scenes.append(sc)
+    cs = CameraSettings.look_at((0.4, 0.4, 1.2), (0.3, 0.3, 0.0), 60.0, z_near=0.01)
+    w, h = 96, 96
+    rs = RenderSettings(w, h, 0, 6, 8, mode=F.RT_MODE_LINEAR_MEAN, seed=4, background_color=(0.1, 0.1, 0.1))
+    cam = camera_from_settings(cs, w, h)
+    gpu = Renderer(cam, Scene(gpu_ctx, scenes[0]), rs).render_sums()
+    cpu, _ = ob.OracleScene(scenes[1]).render(cam, rs, threads=8)
+    assert_images_equal(gpu, cpu)
+    assert len(np.unique(gpu.reshape(-1, 3), axis=0)) > 50  # the texels show
+
+
 def test_batching_and_sample_ranges_do_not_change_the_sums(gpu_ctx, cornell):
     """The image is a pure function of (seed, pixel, sample): splitting the work into small batches, or into
     consecutive sample ranges accumulated into one device buffer, gives bit-identical sums."""
