@@ -247,7 +247,7 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
     if (!c) return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory");
     c->device = device;
     c->flags = flags;
-    uint32_t blocks_per_cu = 8u;
+    uint32_t blocks_per_cu = 12u; // two rounds of the six 256-thread blocks a CU holds at six waves per SIMD
     if (const char *e = std::getenv("RT_BLOCKS_PER_CU")) { // tuning knob for experiments
         long v = std::strtol(e, nullptr, 10);
         if (v >= 1 && v <= 64) blocks_per_cu = (uint32_t)v;

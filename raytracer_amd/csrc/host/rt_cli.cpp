@@ -1,6 +1,6 @@
 // rt_cli — command-line driver with the reference CLI's flags (src/main.rs:38-65):
 //   rt_cli [--bvh-disabled] [--debug] [-W|--width N] [-H|--height N] [-d|--max-depth N] [--spp N]
-//          [-c|--camera N] [--seed N] [--batch] [--device N] [--gpus N] INPUT.gltf [OUTPUT.(ppm|pfm)]
+//          [-c|--camera N] [--seed N] [--batch] [--device N] [--gpus N] INPUT.gltf [OUTPUT.(png|ppm|pfm)]
 // Like `main` it loads the glTF file, builds the BVH, picks the camera and renders progressively
 // (src/main.rs:91-104); instead of streaming to a tev viewer it writes the last report to OUTPUT.  `--batch`
 // runs `Renderer::render` (linear mean) instead.  `--bvh-disabled` is accepted and ignored, as in the reference.
@@ -42,7 +42,7 @@ int main(int argc, char **argv) {
         else if (a == "--gpus") gpus = std::atoi(need(i));
         else if (a == "-h" || a == "--help") {
             std::printf("usage: rt_cli [--bvh-disabled] [--debug] [-W N] [-H N] [-d N] [--spp N] [-c N] [--seed N] [--batch] "
-                        "[--device N] [--gpus N] INPUT.gltf [OUTPUT.ppm|OUTPUT.pfm]\n");
+                        "[--device N] [--gpus N] INPUT.gltf [OUTPUT.png|OUTPUT.ppm|OUTPUT.pfm]\n");
             return 0;
         } else if (!a.empty() && a[0] == '-') {
             std::fprintf(stderr, "unknown flag %s\n", a.c_str());

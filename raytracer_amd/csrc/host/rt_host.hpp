@@ -11,11 +11,14 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 #include "../../../include/rt_mi355x.h"
 
@@ -128,15 +131,53 @@ inline std::vector<uint8_t> pixels_to_rgb8(const std::vector<float> &pixels) {
     return out;
 }
 
-// File sink of `ImageOutput` (src/renderer.rs:178-226): `.pfm` keeps the floats, anything else is written as
-// binary PPM after the 8-bit conversion above.
+// 8-bit RGB PNG (colour type 2, filter 0 on every row, one IDAT chunk deflated by zlib).
+inline std::vector<uint8_t> encode_png_rgb8(const std::vector<uint8_t> &rgb, uint32_t width, uint32_t height) {
+    std::vector<uint8_t> raw((size_t)height * ((size_t)width * 3 + 1));
+    for (uint32_t y = 0; y < height; ++y) {
+        uint8_t *row = raw.data() + (size_t)y * ((size_t)width * 3 + 1);
+        row[0] = 0;
+        std::memcpy(row + 1, rgb.data() + (size_t)y * width * 3, (size_t)width * 3);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) throw Error(RT_ERR_IO, "zlib compress failed");
+    z.resize(zlen);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    auto be32 = [&](uint32_t v) {
+        for (int s = 24; s >= 0; s -= 8) out.push_back((uint8_t)(v >> s));
+    };
+    auto chunk = [&](const char *tag, const std::vector<uint8_t> &body) {
+        be32((uint32_t)body.size());
+        const size_t start = out.size();
+        out.insert(out.end(), tag, tag + 4);
+        out.insert(out.end(), body.begin(), body.end());
+        be32((uint32_t)crc32(0L, out.data() + start, (uInt)(out.size() - start)));
+    };
+    std::vector<uint8_t> ihdr;
+    for (uint32_t v : {width, height})
+        for (int s = 24; s >= 0; s -= 8) ihdr.push_back((uint8_t)(v >> s));
+    for (uint8_t b : {8, 2, 0, 0, 0}) ihdr.push_back(b);
+    chunk("IHDR", ihdr);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    return out;
+}
+
+// File sink of `ImageOutput` (src/renderer.rs:178-226): the reference converts to 8 bits with pixels_to_image
+// and lets the image crate pick the format from the extension.  Here `.png` and `.ppm` (any other extension)
+// hold those 8-bit values and `.pfm` keeps the floats.
 struct ImageOutput {
     std::string path;
     void write(const std::vector<float> &pixels, uint32_t width, uint32_t height) const {
         FILE *f = std::fopen(path.c_str(), "wb");
         if (!f) throw Error(RT_ERR_IO, "cannot open " + path);
         const bool pfm = path.size() >= 4 && path.compare(path.size() - 4, 4, ".pfm") == 0;
-        if (pfm) {
+        const bool png = path.size() >= 4 && path.compare(path.size() - 4, 4, ".png") == 0;
+        if (png) {
+            std::vector<uint8_t> file = encode_png_rgb8(pixels_to_rgb8(pixels), width, height);
+            std::fwrite(file.data(), 1, file.size(), f);
+        } else if (pfm) {
             std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);
             for (uint32_t j = height; j-- > 0;) // PFM rows run bottom to top
                 std::fwrite(pixels.data() + (size_t)j * width * 3, sizeof(float), (size_t)width * 3, f);

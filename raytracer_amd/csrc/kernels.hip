@@ -46,6 +46,27 @@ __device__ __forceinline__ bool box_hit(float4 nlo, float4 nhi, V3 o, V3 inv, fl
     return !(hi <= lo);
 }
 
+// The same test on a node stored as (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, skip, leaf) — the layout of the LDS
+// copy of the node table.  The two planes of an axis then sit in one register pair, which is the operand shape
+// of the packed binary32 subtract and multiply; operations and their order per lane are unchanged.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool box_hit_pairs(float4 a, float4 b, V3 o, V3 inv, float lo, float hi) {
+    v2f tx = (v2f{a.x, a.y} - v2f{o.x, o.x}) * v2f{inv.x, inv.x};
+    v2f ty = (v2f{a.z, a.w} - v2f{o.y, o.y}) * v2f{inv.y, inv.y};
+    v2f tz = (v2f{b.x, b.y} - v2f{o.z, o.z}) * v2f{inv.z, inv.z};
+    bool s = tx.x < tx.y;
+    lo = fmaxf(lo, s ? tx.x : tx.y);
+    hi = fminf(hi, s ? tx.y : tx.x);
+    s = ty.x < ty.y;
+    lo = fmaxf(lo, s ? ty.x : ty.y);
+    hi = fminf(hi, s ? ty.y : ty.x);
+    s = tz.x < tz.y;
+    lo = fmaxf(lo, s ? tz.x : tz.y);
+    hi = fminf(hi, s ? tz.y : tz.x);
+    return !(hi <= lo);
+}
+
 struct Closest {
     float t;
     uint32_t slot;
@@ -102,7 +123,8 @@ __device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uin
 // shrinking `hit_range.max`: the reference hands the right sibling max = the left hit's distance, and every
 // later node therefore sees the closest distance found so far in visiting order.
 // `nodes` / `prims` may point at HBM or at a copy of the tables in LDS.
-template <bool COUNT>
+// PAIRS: `nodes` is the LDS copy in the paired layout of box_hit_pairs.
+template <bool COUNT, bool PAIRS>
 __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ prims,
                                             uint32_t n_nodes, V3 o, V3 d, float tmin, float tmax,
                                             uint32_t &n_nodes_visited, uint32_t &n_tri, uint32_t &n_sph) {
@@ -114,7 +136,7 @@ __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, co
         float4 nlo = nodes[2 * idx];
         float4 nhi = nodes[2 * idx + 1];
         if (COUNT) ++n_nodes_visited;
-        bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+        bool hit = PAIRS ? box_hit_pairs(nlo, nhi, o, inv, tmin, best.t) : box_hit(nlo, nhi, o, inv, tmin, best.t);
         uint32_t leaf = f2u(nhi.w);
         if (hit && leaf != kInterior) {
             uint32_t slot = leaf & ~kSphereBit;
@@ -126,7 +148,7 @@ __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, co
                 tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
             }
         }
-        idx = hit ? idx + 1 : f2u(nlo.w);
+        idx = hit ? idx + 1 : f2u(PAIRS ? nhi.z : nlo.w);
     }
     return best;
 }
@@ -475,7 +497,11 @@ __device__ __forceinline__ QueueCursor queue_begin(const QueueView &q) {
 __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *lds, const float4 *&nodes,
                                                    const float4 *&prims) {
     const uint32_t n4_nodes = 2u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
-    for (uint32_t i = threadIdx.x; i < n4_nodes; i += kBlock) lds[i] = nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += kBlock) { // into the paired layout of box_hit_pairs
+        const float4 lo = nodes[2 * i], hi = nodes[2 * i + 1];
+        lds[2 * i] = make_float4(lo.x, hi.x, lo.y, hi.y);
+        lds[2 * i + 1] = make_float4(lo.z, hi.z, lo.w, hi.w);
+    }
     for (uint32_t i = threadIdx.x; i < n4_prims; i += kBlock) lds[n4_nodes + i] = prims[i];
     nodes = lds;
     prims = lds + n4_nodes;
@@ -564,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
             float4 nlo = nodes[2 * idx];
             float4 nhi = nodes[2 * idx + 1];
             if (COUNT) ++c_nodes;
-            bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+            bool hit = LDS_SCENE ? box_hit_pairs(nlo, nhi, o, inv, tmin, best.t) : box_hit(nlo, nhi, o, inv, tmin, best.t);
             uint32_t leaf = f2u(nhi.w);
             if (hit && leaf != kInterior) {
                 uint32_t ps = leaf & ~kSphereBit;
@@ -576,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
                     tri_test(prims + 3 * (size_t)ps, ps, o, d, tmin, best);
                 }
             }
-            idx = hit ? idx + 1 : f2u(nlo.w);
+            idx = hit ? idx + 1 : f2u(LDS_SCENE ? nhi.z : nlo.w);
             if (idx >= end) {
                 hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
                 have = false;
@@ -629,7 +655,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_world(SceneDev sc, const floa
 enum : int { kPathEnded = 0, kPathAlive = 1, kPathEndedByEarlyMiss = 2 };
 
 template <bool NEED_UV, bool HAS_MIX>
-__device__ __forceinline__ int shade_path(const SceneDev &sc, const float4 *__restrict__ nodes,
+__device__ __forceinline__ int shade_path(const SceneDev &sc, float4 root_lo, float4 root_hi,
                                           const float4 *__restrict__ prims, const RenderParams &P, const PathState &st,
                                           uint32_t slot, V3 o, V3 d, V3 beta, uint32_t k, uint32_t flags, uint32_t depth,
                                           uint32_t s_local, uint32_t pixel, const Closest &best) {
@@ -660,7 +686,7 @@ __device__ __forceinline__ int shade_path(const SceneDev &sc, const float4 *__re
             if (alive) {
                 V3 nd = sr.direction;
                 V3 ninv = V3{1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z};
-                if (!box_hit(nodes[0], nodes[1], s.point, ninv, P.z_near, P.z_far)) {
+                if (!box_hit(root_lo, root_hi, s.point, ninv, P.z_near, P.z_far)) {
                     alive = false;
                     early_miss = true;
                     l = ld3(P.background);
@@ -725,7 +751,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
             float4 b4 = st.beta[slot];
             Closest best{h.x, f2u(h.y), h.z, h.w};
             const uint32_t s_local = f2u(d4.w) >> 16;
-            alive = shade_path<NEED_UV, HAS_MIX>(sc, nodes, prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
+            alive = shade_path<NEED_UV, HAS_MIX>(sc, nodes[0], nodes[1], prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
                                         f2u(o4.w) >> 24, f2u(d4.w) & 0xFFFFu, s_local, slot - s_local * P.npix, best);
         }
         compact_survivors(alive, slot, lane, &s_out, &s_early, queue_out, c.seg);
@@ -742,14 +768,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
 // the hit stay in registers between traversal and shading.  With LDS_SCENE the node and primitive tables are
 // first copied into LDS and traversal reads them there.
 // ------------------------------------------------------------------------------------------------------
+// Six waves per SIMD: the kernel needs 81 VGPRs unconstrained, one over the 80 that let a sixth wave in.
 template <bool FIRST, bool LDS_SCENE, bool NEED_UV>
-__global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
                                                    uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out,
                                                    uint32_t *__restrict__ early_out) {
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_out, s_early;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
+    const float4 root_lo = nodes[0], root_hi = nodes[1]; // the root box in the table's own layout, for early misses
     if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
     if (threadIdx.x == 0) {
         s_out = 0u;
@@ -784,8 +812,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev sc, RenderParams P, 
                 pixel = slot - s_local * P.npix;
             }
             uint32_t c0 = 0, c1 = 0, c2 = 0;
-            Closest best = traverse<false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-            alive = shade_path<NEED_UV, false>(sc, nodes, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
+            Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+            alive = shade_path<NEED_UV, false>(sc, root_lo, root_hi, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
         }
         compact_survivors(alive, slot, lane, &s_out, &s_early, queue_out, c.seg);
     }

@@ -494,6 +494,15 @@ def test_cpp_host_cli(cornell, tmp_path):
     out = str(tmp_path / "img.ppm")
     r = subprocess.run([cli, "-W", "16", "-H", "12", "--spp", "2", asset, out], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and open(out, "rb").read().startswith(b"P6\n16 12\n255\n")
+    # PNG sink: the same 8-bit values as the PPM (pixels_to_image, src/renderer.rs:173-176)
+    from raytracer_amd.png import decode_png_rgb8
+
+    png_out, ppm_out = str(tmp_path / "img.png"), str(tmp_path / "same.ppm")
+    for o in (png_out, ppm_out):
+        r = subprocess.run([cli, "-W", "16", "-H", "12", "--spp", "2", asset, o], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    ppm = np.frombuffer(open(ppm_out, "rb").read()[len(b"P6\n16 12\n255\n"):], dtype=np.uint8).reshape(12, 16, 3)
+    assert np.array_equal(decode_png_rgb8(open(png_out, "rb").read()), ppm) and ppm.max() > 0
     r = subprocess.run([cli, "/nonexistent.gltf"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "error" in r.stderr
 
