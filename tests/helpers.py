@@ -157,3 +157,79 @@ def encode_png(samples, ctype, depth=8, palette=None, interlace=False, filters=(
     half = len(data) // 2
     png += chunk(b"tEXt", b"Comment\0two IDAT chunks follow") + chunk(b"IDAT", data[:half]) + chunk(b"IDAT", data[half:])
     return png + chunk(b"IEND", b"")
+
+
+def random_scene(seed):
+    """A small random scene for differential testing: meshes of random triangles (some with vertex normals and
+    texture coordinates, some coplanar and axis-aligned so the 0.001 padding and exact ties occur, some
+    duplicated or degenerate), random spheres, and every material and texture kind.  Returns the scene and
+    camera settings looking at it."""
+    from raytracer_amd import SceneDescription, Sphere
+    from raytracer_amd.scene import CameraSettings, Texture, TriangleMesh
+
+    rng = np.random.default_rng(seed)
+    sc = SceneDescription(spheres_first=bool(rng.integers(0, 2)))
+    f32 = np.float32
+
+    def colour():
+        return tuple(rng.random(3).astype(f32))
+
+    def material(depth=0):
+        kind = rng.integers(0, 7 if depth < 3 else 5)
+        if kind == 0:
+            return sc.lambertian(colour())
+        if kind == 1:
+            return sc.metal(colour(), rng.random() * 0.6)
+        if kind == 2:
+            return sc.dielectric(1.0 + rng.random())
+        if kind == 3:
+            return sc.diffuse_light(colour(), 1.0 + 10 * rng.random())
+        if kind == 4:
+            even = sc.add_texture(Texture.solid_color(colour()))
+            odd = sc.add_texture(Texture.solid_color(colour()))
+            if rng.random() < 0.5:
+                tex = sc.add_texture(Texture.checkerboard(1.0 / (0.05 + rng.random()), even, odd))
+            else:
+                tex = sc.add_texture(Texture.from_image(rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 3))))
+            return sc.lambertian_texture(tex)
+        return sc.mix(material(depth + 1), material(depth + 1), float(rng.choice([0.0, 1.0, 0.25, 0.5, rng.random()])))
+
+    for _ in range(int(rng.integers(1, 6))):
+        nf = int(rng.integers(1, 60))
+        style = rng.integers(0, 4)
+        if style == 0:  # free triangles
+            pos = (rng.random((nf * 3, 3)) * 4 - 2).astype(f32)
+        elif style == 1:  # small triangles
+            c = rng.random((nf, 1, 3)) * 4 - 2
+            pos = (c + (rng.random((nf, 3, 3)) - 0.5) * 0.4).reshape(-1, 3).astype(f32)
+        elif style == 2:  # an axis-aligned plane cut into triangles that share edges and vertices exactly
+            axis = int(rng.integers(0, 3))
+            g = int(rng.integers(2, 6))
+            u, v = np.meshgrid(np.linspace(-2, 2, g), np.linspace(-2, 2, g), indexing="ij")
+            grid = np.zeros((g, g, 3))
+            grid[..., (axis + 1) % 3] = u
+            grid[..., (axis + 2) % 3] = v
+            grid[..., axis] = rng.choice([-2.0, 0.0, 1.5])
+            tris = []
+            for i in range(g - 1):
+                for j in range(g - 1):
+                    a, b, c, d = grid[i, j], grid[i + 1, j], grid[i + 1, j + 1], grid[i, j + 1]
+                    tris += [a, b, c, a, c, d]
+            pos = np.array(tris, dtype=f32)
+            nf = len(pos) // 3
+        else:  # duplicates and degenerate triangles
+            base = (rng.random((3, 3)) * 3 - 1.5).astype(f32)
+            pos = np.concatenate([base, base, base[[0, 0, 1]], base[[0, 1, 1]] * f32(1.0), (rng.random((3, 3)) * 3 - 1.5).astype(f32)])
+            nf = len(pos) // 3
+        idx = np.arange(nf * 3, dtype=np.uint32).reshape(nf, 3)
+        with_attrs = rng.random() < 0.5
+        normals = rng.normal(size=(nf * 3, 3)).astype(f32) if with_attrs else np.zeros((0, 3), f32)
+        uvs = (rng.random((nf * 3, 2)) * 1.5 - 0.25).astype(f32) if with_attrs else np.zeros((0, 2), f32)
+        sc.meshes.append(TriangleMesh(pos, idx, normals, uvs, material()))
+    for _ in range(int(rng.integers(0, 12))):
+        sc.spheres.append(Sphere(tuple((rng.random(3) * 4 - 2).astype(f32)), float(f32(0.05 + rng.random() * 0.8)), material()))
+    eye = rng.normal(size=3)
+    eye = eye / np.linalg.norm(eye) * (4.0 + 3.0 * rng.random())
+    cs = CameraSettings.look_at(tuple(eye), (0.0, 0.0, 0.0), 40.0 + 30.0 * rng.random(), focus_dist=float(np.linalg.norm(eye)),
+                                defocus_angle=float(rng.choice([0.0, 0.0, 2.0])), z_near=1e-3)
+    return sc, cs

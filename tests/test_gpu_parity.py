@@ -342,6 +342,32 @@ def test_png_textured_gltf_end_to_end(gpu_ctx, tmp_path):
     assert len(np.unique(gpu.reshape(-1, 3), axis=0)) > 50  # the texels show
 
 
+@pytest.mark.parametrize("block", [0, 1, 2, 3])
+def test_random_scenes_differential(gpu_ctx, block):
+    """Differential test on random scenes (helpers.random_scene): every material and texture kind, Mix trees,
+    spheres before or after the meshes, shared edges, duplicated and degenerate triangles, defocus.  Closest
+    hits of incoherent rays and rendered sums must equal the oracle's bit for bit, with and without the BVH."""
+    from helpers import random_scene
+
+    for seed in range(block * 6, block * 6 + 6):
+        desc, cs = random_scene(seed)
+        g, o = both(gpu_ctx, desc)
+        rays = random_rays(6000, (-2.5, -2.5, -2.5), (2.5, 2.5, 2.5), seed=seed, axis_aligned_fraction=0.2)
+        for use_bvh in (True, False):
+            got, _ = g.trace_closest(rays, 1e-3, np.inf, use_bvh=use_bvh)
+            want, _ = o.trace_closest(rays, 1e-3, np.inf, use_bvh=use_bvh)
+            assert_hits_equal(got, want)
+        w, h = 72, 56
+        cam = camera_from_settings(cs, w, h)
+        mode = F.RT_MODE_GAMMA_PER_SAMPLE if seed % 2 else F.RT_MODE_LINEAR_MEAN
+        rs = RenderSettings(w, h, 0, 12, 5, mode=mode, seed=100 + seed, background_color=(0.2, 0.3, 0.4))
+        r = Renderer(cam, g, rs)
+        gpu = r.render_sums()
+        cpu, cst = o.render(cam, rs, threads=16)
+        assert_images_equal(gpu, cpu)
+        assert r.last_stats.rays_traced == cst.rays_traced
+
+
 def test_batching_and_sample_ranges_do_not_change_the_sums(gpu_ctx, cornell):
     """The image is a pure function of (seed, pixel, sample): splitting the work into small batches, or into
     consecutive sample ranges accumulated into one device buffer, gives bit-identical sums."""

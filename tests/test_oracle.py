@@ -334,3 +334,20 @@ def test_mix_material_semantics(cornell):
                 m = sc.mix(m, sc.dielectric(1.5), 0.5)
             return m, m
         render(deep)
+
+
+def test_random_scenes_bvh_against_world_scan():
+    """On random scenes (helpers.random_scene) the BVH walk and the linear scan of `World::hit` find the same
+    distance for every ray, and the same primitive unless two primitives are hit at the same distance."""
+    from helpers import random_rays, random_scene
+
+    for seed in range(8):
+        desc, _ = random_scene(seed)
+        o = ob.OracleScene(desc)
+        rays = random_rays(3000, (-2.5, -2.5, -2.5), (2.5, 2.5, 2.5), seed=seed, axis_aligned_fraction=0.2)
+        a, _ = o.trace_closest(rays, 1e-3, np.inf, use_bvh=True)
+        b, _ = o.trace_closest(rays, 1e-3, np.inf, use_bvh=False)
+        assert np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32))
+        differ = a["prim_id"] != b["prim_id"]
+        assert differ.mean() < 0.02  # exact ties only (shared edges, duplicated triangles)
+        assert (a["prim_id"] != F.RT_MISS).mean() > 0.02
