@@ -290,9 +290,10 @@ int rt_context_set_pipeline(rt_context *ctx, uint32_t pipeline);
 int rt_context_set_timed_bounces(rt_context *ctx, uint32_t bounces);
 
 /* `SceneDescription` after `build_bvh(BvhType::Tree)` (src/scene.rs:29-49, src/main.rs:91): validates the
- * description, builds the BVH on the host by the reference's rule (src/bvh.rs:248-285, src/aabb.rs:26-93,
- * 129-137; equal sort keys are ordered by ascending primitive ID), flattens it into the device tables and
- * uploads them. */
+ * description, builds the BVH by the reference's rule (src/bvh.rs:248-285, src/aabb.rs:26-93, 129-137; equal
+ * sort keys are ordered by ascending primitive ID), flattens it into the device tables and uploads them.
+ * Scenes of at least 65536 primitives (environment variable RT_DEVICE_BUILD_MIN_PRIMS) get the tree built on
+ * the GPU, smaller ones on the host; the two builders produce the same tree bit for bit. */
 int rt_scene_create(rt_context *ctx, const rt_scene_desc *desc, rt_scene **out);
 int rt_scene_destroy(rt_scene *scene);
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);

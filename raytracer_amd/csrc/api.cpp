@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
+#include "bvh_build.h"
 #include "kernels.h"
 #include "rt_device.h"
 #include "rt_math.h"
@@ -328,24 +329,57 @@ RT_API int rt_context_set_max_paths(rt_context *c, uint64_t max_paths) {
 RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **out) {
     if (!c || !desc || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
     *out = nullptr;
-    rt::HostScene hs;
-    std::string err;
-    int rc;
-    try {
-        rc = rt::build_host_scene(desc, hs, err);
-    } catch (const std::bad_alloc &) {
-        return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory while building the scene");
-    } catch (const std::exception &e) {
-        return set_error(RT_ERR_INVALID_ARGUMENT, "scene build failed: %s", e.what());
-    }
-    if (rc) return set_error(rc, "%s", err.c_str());
-
     DeviceGuard guard(c->device);
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory");
     s->device = c->device;
+
+    // Scenes of at least RT_DEVICE_BUILD_MIN_PRIMS primitives (default 65536) get their tree built on the GPU
+    // (bvh_build.hip); smaller ones by the host builder.  Both produce the same tree.
+    uint64_t device_min = 1ull << 16;
+    if (const char *e = std::getenv("RT_DEVICE_BUILD_MIN_PRIMS")) device_min = std::strtoull(e, nullptr, 10);
+    rt::Node *d_nodes = nullptr;
+    uint64_t n_nodes_device = 0;
+    rt::ExternalTreeBuilder on_device = [&](const rt::BuildBox *boxes, uint32_t n, uint32_t sphere_begin, uint32_t sphere_end,
+                                            std::vector<uint32_t> &order, uint32_t &depth, std::string &e) -> int {
+        void *p = nullptr;
+        n_nodes_device = 2ull * n - 1;
+        if (hipMalloc(&p, n_nodes_device * sizeof(rt::Node)) != hipSuccess) {
+            e = "out of device memory for the BVH nodes";
+            return RT_ERR_OUT_OF_MEMORY;
+        }
+        s->blocks[s->n_blocks++] = p;
+        d_nodes = static_cast<rt::Node *>(p);
+        return rt::build_bvh_device(c->stream, boxes, n, sphere_begin, sphere_end, d_nodes, order.data(), &depth, e);
+    };
+
+    rt::HostScene hs;
+    std::string err;
+    int rc;
+    try {
+        rc = rt::build_host_scene(desc, hs, err, &on_device, device_min);
+    } catch (const std::bad_alloc &) {
+        rt_scene_destroy(s);
+        return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory while building the scene");
+    } catch (const std::exception &e) {
+        rt_scene_destroy(s);
+        return set_error(RT_ERR_INVALID_ARGUMENT, "scene build failed: %s", e.what());
+    }
+    if (rc) {
+        rt_scene_destroy(s);
+        return set_error(rc, "%s", err.c_str());
+    }
+
     uint64_t bytes = 0;
-    rc = upload(s, hs.nodes, &s->dev.nodes, bytes);
+    rt::Node root{};
+    if (d_nodes) {
+        s->dev.nodes = d_nodes;
+        bytes += n_nodes_device * sizeof(rt::Node);
+        if (hipMemcpy(&root, d_nodes, sizeof root, hipMemcpyDeviceToHost) != hipSuccess) rc = set_error(RT_ERR_DEVICE, "reading the root node failed");
+    } else {
+        root = hs.nodes[0];
+        rc = upload(s, hs.nodes, &s->dev.nodes, bytes);
+    }
     if (!rc) rc = upload(s, hs.prims, &s->dev.prims, bytes);
     if (!rc) rc = upload(s, hs.tri_shade, &s->dev.tri_shade, bytes);
     if (!rc) rc = upload(s, hs.materials, &s->dev.materials, bytes);
@@ -356,7 +390,7 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
         rt_scene_destroy(s);
         return rc;
     }
-    s->dev.n_nodes = (uint32_t)hs.nodes.size();
+    s->dev.n_nodes = d_nodes ? (uint32_t)n_nodes_device : (uint32_t)hs.nodes.size();
     s->dev.n_prims = (uint32_t)hs.prims.size();
     s->dev.n_materials = (uint32_t)hs.materials.size();
     s->dev.n_textures = (uint32_t)hs.textures.size();
@@ -367,8 +401,8 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
     s->info.num_spheres = hs.n_spheres;
     s->info.num_nodes = s->dev.n_nodes;
     s->info.depth = hs.depth;
-    std::memcpy(s->info.bounds_min, hs.nodes[0].bmin, 12);
-    std::memcpy(s->info.bounds_max, hs.nodes[0].bmax, 12);
+    std::memcpy(s->info.bounds_min, root.bmin, 12);
+    std::memcpy(s->info.bounds_max, root.bmax, 12);
     s->info.device_bytes = bytes;
     *out = s;
     return RT_OK;

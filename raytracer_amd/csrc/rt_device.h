@@ -22,6 +22,12 @@ struct alignas(16) Node {
 };
 static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 
+// An object's own bounding box (`Hittable::bounding_box`), already padded; input of the tree builders.
+struct BuildBox {
+    float lo[3];
+    float hi[3];
+};
+
 // One primitive of the intersection table, 48 bytes, stored in leaf (pre-order) order.
 //   triangle: a = v0.xyz | prim_id, b = e1.xyz | material, c = e2.xyz | flags    (e1 = v1 - v0, e2 = v2 - v0,
 //             the same subtractions TriangleRef::hit performs per call, src/object/triangle_mesh.rs:144-145)

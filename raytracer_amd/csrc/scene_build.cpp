@@ -4,7 +4,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -17,10 +20,24 @@ namespace rt {
 namespace {
 
 // ---- Range / Aabb construction (src/range.rs:16-21,35-37,54-60; src/aabb.rs:26-93,129-137) -------------
-struct Box {
-    float lo[3];
-    float hi[3];
-};
+using Box = BuildBox;
+
+// Runs fn(begin, end) over [0, n) on the host's cores (one call when the range is small).
+template <class Fn> void parallel_for(uint64_t n, Fn fn) {
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads > 32) threads = 32;
+    if (threads < 2 || n < (1u << 16)) {
+        fn((uint64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const uint64_t chunk = (n + threads - 1) / threads;
+    for (unsigned t = 0; t < threads; ++t) {
+        const uint64_t b = t * chunk, e = std::min(n, b + chunk);
+        if (b < e) pool.emplace_back([=] { fn(b, e); });
+    }
+    for (auto &t : pool) t.join();
+}
 
 inline void pad_axis(float &lo, float &hi) {
     const float delta = 0.001f;
@@ -198,7 +215,8 @@ inline void store3(float *dst, V3 v) {
 
 } // namespace
 
-int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err) {
+int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err, const ExternalTreeBuilder *external,
+                     uint64_t external_min_objects) {
     if (!d) return fail(err, RT_ERR_INVALID_ARGUMENT, "null scene description");
     if ((d->num_meshes && !d->meshes) || (d->num_spheres && !d->spheres) || (d->num_materials && !d->materials) ||
         (d->num_textures && !d->textures))
@@ -228,6 +246,17 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err) {
     for (uint32_t i = 0; i < d->num_spheres; ++i)
         if (d->spheres[i].material < 0 || (uint32_t)d->spheres[i].material >= d->num_materials)
             return fail(err, RT_ERR_INVALID_ARGUMENT, "sphere material out of range");
+
+    // RT_BUILD_TIMING=1 prints how long each phase of the host build takes
+    const bool timing = std::getenv("RT_BUILD_TIMING") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase_done = [&](const char *name) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rt build] %-28s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(now - t_phase).count());
+        t_phase = now;
+    };
+    phase_done("validation");
 
     // ---- materials and textures ----
     out.need_uv = false;
@@ -287,7 +316,8 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err) {
     if (!d->spheres_first) push_spheres();
 
     std::vector<Box> boxes(n_obj);
-    for (uint64_t i = 0; i < n_obj; ++i) {
+    parallel_for(n_obj, [&](uint64_t begin, uint64_t end) {
+    for (uint64_t i = begin; i < end; ++i) {
         const Obj &o = objs[i];
         if (o.sphere) { // Sphere::new (src/object/sphere.rs:21-24)
             const rt_sphere &s = d->spheres[o.mesh_or_sphere];
@@ -301,26 +331,40 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err) {
             boxes[i] = box_union(box_from_points(v0, v1), box_from_points(v2, v2));
         }
     }
+    });
+
+    phase_done("object list and boxes");
 
     // ---- BVH ----
-    out.nodes.assign(2 * n_obj - 1, Node{});
     std::vector<uint32_t> order(n_obj);
-    for (uint64_t i = 0; i < n_obj; ++i) order[i] = (uint32_t)i;
-    int hw = (int)std::thread::hardware_concurrency();
-    if (hw < 1) hw = 1;
-    if (hw > 32) hw = 32;
-    Builder builder(boxes, out.nodes, order, hw - 1);
-    builder.build(0, (uint32_t)n_obj, 0, 1);
-    out.depth = builder.max_level.load();
+    if (external && n_obj >= external_min_objects) {
+        out.nodes.clear();
+        const uint32_t sphere_begin = d->spheres_first ? 0u : (uint32_t)n_tri;
+        if (int rc = (*external)(boxes.data(), (uint32_t)n_obj, sphere_begin, sphere_begin + d->num_spheres, order, out.depth, err))
+            return rc;
+    } else {
+        out.nodes.assign(2 * n_obj - 1, Node{});
+        for (uint64_t i = 0; i < n_obj; ++i) order[i] = (uint32_t)i;
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        if (hw > 32) hw = 32;
+        Builder builder(boxes, out.nodes, order, hw - 1);
+        builder.build(0, (uint32_t)n_obj, 0, 1);
+        out.depth = builder.max_level.load();
+    }
+    std::vector<Box>().swap(boxes);
     out.n_triangles = (uint32_t)n_tri;
     out.n_spheres = d->num_spheres;
+
+    phase_done("BVH (median split)");
 
     // ---- leaf-ordered primitive tables ----
     out.prims.assign(n_obj, Prim{});
     out.tri_shade.assign(n_obj, TriShade{});
     out.slot_of_prim.assign(n_obj, 0);
     out.prim_of_slot = order;
-    for (uint64_t slot = 0; slot < n_obj; ++slot) {
+    parallel_for(n_obj, [&](uint64_t begin, uint64_t end) {
+    for (uint64_t slot = begin; slot < end; ++slot) {
         const uint32_t id = order[slot];
         const Obj &o = objs[id];
         Prim &p = out.prims[slot];
@@ -363,9 +407,11 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err) {
             out.slot_of_prim[id] = (uint32_t)slot;
         }
     }
-    // leaves: add the sphere bit now that the tables are known
+    });
+    // leaves: add the sphere bit now that the tables are known (an external builder sets it itself)
     for (Node &n : out.nodes)
         if (n.leaf != kInterior && objs[order[n.leaf]].sphere) n.leaf |= kSphereBit;
+    phase_done("leaf-ordered tables");
     return RT_OK;
 }
 

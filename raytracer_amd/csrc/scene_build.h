@@ -3,6 +3,7 @@
 
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -28,7 +29,16 @@ struct HostScene {
     bool has_mix = false;  // some material is a Mix
 };
 
-// Validates `desc` and fills `out`.  Returns an rt_status; on failure `err` holds the message.
-int build_host_scene(const rt_scene_desc *desc, HostScene &out, std::string &err);
+// A tree builder that runs elsewhere (the GPU): gets the objects' boxes in object-list order and the ID range
+// of the spheres, keeps the node table to itself and returns the leaf order (object ID per leaf slot) and the
+// number of levels.
+using ExternalTreeBuilder = std::function<int(const BuildBox *boxes, uint32_t n, uint32_t sphere_begin, uint32_t sphere_end,
+                                              std::vector<uint32_t> &order, uint32_t &depth, std::string &err)>;
+
+// Validates `desc` and fills `out`.  Returns an rt_status; on failure `err` holds the message.  With `external`
+// and at least `external_min_objects` objects the tree is built by it instead of the host builder and
+// `out.nodes` stays empty.
+int build_host_scene(const rt_scene_desc *desc, HostScene &out, std::string &err, const ExternalTreeBuilder *external = nullptr,
+                     uint64_t external_min_objects = 0);
 
 } // namespace rt

@@ -67,6 +67,37 @@ def test_bvh_tables_equal_the_oracles(gpu_ctx, cornell, teapot):
     check_bvh_structure(gb, gp, gs, 36)
 
 
+def test_device_tree_builder_equals_the_host_builder(gpu_ctx, cornell, teapot, monkeypatch):
+    """The GPU tree builder (level-by-level radix sorts, csrc/bvh_build.hip) and the host builder give the same
+    node table and leaf order, bit for bit, which is also the oracle's: thin axis-aligned walls (the 0.001
+    padding fires inside the fold), spheres before and after meshes, duplicated and degenerate triangles, exact
+    key ties, one and two objects, and a soup large enough for the block-per-segment levels."""
+    from helpers import random_scene
+
+    descs = [cornell, teapot, rtiow_final_scene()[0], triangle_soup(150_000)[0]] + [random_scene(s)[0] for s in range(10)]
+    one = SceneDescription()
+    one.meshes.append(TriangleMesh(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32),
+                                   np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), one.lambertian((0.5, 0.5, 0.5))))
+    two = SceneDescription(list(one.meshes), [Sphere((0.0, 0.0, 1.0), 0.5, 0)], list(one.materials), list(one.textures))
+    for desc in descs + [one, two]:
+        tables = []
+        for min_prims in ("1", "4000000000"):
+            monkeypatch.setenv("RT_DEVICE_BUILD_MIN_PRIMS", min_prims)
+            sc = Scene(gpu_ctx, desc)
+            tables.append(sc.export_bvh() + (sc.info().depth,))
+        (db, dp, ds, dd), (hb, hp, hs, hd) = tables
+        assert np.array_equal(db.view(np.uint32), hb.view(np.uint32)) and np.array_equal(dp, hp) and np.array_equal(ds, hs)
+        assert dd == hd
+        ob_, op, os_ = ob.OracleScene(desc).export_bvh()
+        assert np.array_equal(db.view(np.uint32), ob_.view(np.uint32)) and np.array_equal(dp, op) and np.array_equal(ds, os_)
+    # closest hits through a device-built tree, spheres included
+    monkeypatch.setenv("RT_DEVICE_BUILD_MIN_PRIMS", "1")
+    desc, _ = rtiow_final_scene()
+    g, o = both(gpu_ctx, desc)
+    rays = random_rays(20000, (-12, 0, -12), (12, 3, 12), seed=2)
+    assert_hits_equal(g.trace_closest(rays, 1e-3, np.inf)[0], o.trace_closest(rays, 1e-3, np.inf)[0])
+
+
 @pytest.mark.parametrize("name", ["cornell", "teapot"])
 def test_primary_rays(gpu_ctx, cornell, teapot, name):
     desc = {"cornell": cornell, "teapot": teapot}[name]
