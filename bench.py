@@ -201,7 +201,8 @@ def main():
         traffic_per_ray = None
         tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic_cornell1080p.json")
         if os.path.exists(tj):
-            kern = json.load(open(tj)).get("kernels", {}).get("k_bounce")
+            kernels = json.load(open(tj)).get("kernels", {})
+            kern = kernels.get("k_paths") or kernels.get("k_bounce")
             if kern:
                 traffic_per_ray = kern["hbm_read_bytes_per_ray"] + kern["hbm_write_bytes_per_ray"]
 
@@ -218,6 +219,13 @@ def main():
                       acc["timed_launches"] - acc["first_launches"])
         first = group(acc["first_ms"], acc["first_rays"], acc["first_launches"])
         avg_launch_ms, rays_per_launch, achieved = later
+        one_launch_per_batch = acc["pipeline"] in (F.RT_PIPELINE_PATHS, F.RT_PIPELINE_PATHS_LDS)
+        if one_launch_per_batch:
+            kernel_name = ("k_paths<true,false> (one launch per batch of 32 spp: generate + extend + shade of every bounce; "
+                           "BVH and triangles staged in LDS)")
+        else:
+            kernel_name = ("k_bounce<false,true,false> (extend + shade of bounces 1..%d of each batch, BVH and triangles "
+                           "staged in LDS)" % (TIMED_BOUNCES - 1))
         img = (total / float(spp * world * (args.steps + args.warmup))).cpu().numpy()
         finite = np.isfinite(img)
         out = {
@@ -241,7 +249,7 @@ def main():
             "mpaths_per_s": paths_all / elapsed / 1e6,
             "rays_per_path": rays_all / max(1, paths_all),
             "time_to_1024spp_s": 1024.0 * npix / (paths_all / elapsed),
-            "pipeline": {2: "fused", 3: "fused+lds"}.get(acc["pipeline"], str(acc["pipeline"])),
+            "pipeline": {2: "fused", 3: "fused+lds", 7: "paths", 8: "paths+lds"}.get(acc["pipeline"], str(acc["pipeline"])),
             "kernel_ms_rank0": {k: acc[k] for k in ("gpu_ms", "bounce_ms", "generate_ms", "extend_ms", "shade_ms",
                                                     "accumulate_ms")},
             "image_check": {"finite_mean": float(img[finite].mean()), "inf_fraction": float(np.isinf(img).mean()),
@@ -251,12 +259,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None if traffic_per_ray is None else traffic_per_ray * rays_per_launch,
                 "traffic_unit": "bytes per launch (HBM, PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_cornell1080p.json)",
-                "kernel": "k_bounce<false,true,false> (extend + shade of bounces 1..%d of each batch, BVH and triangles "
-                          "staged in LDS)" % (TIMED_BOUNCES - 1),
+                "kernel": kernel_name,
                 "avg_launch_ms": avg_launch_ms, "rays_per_launch": rays_per_launch,
-                "first_bounce_kernel": {"kernel": "k_bounce<true,true,false> (generate + extend + shade of bounce 0)",
-                                        "avg_launch_ms": first[0], "rays_per_launch": first[1], "achieved": first[2],
-                                        "frac": first[2] / HBM_PEAK_GBS, "launches": acc["first_launches"]},
+                "first_bounce_kernel": None if one_launch_per_batch else {
+                    "kernel": "k_bounce<true,true,false> (generate + extend + shade of bounce 0)",
+                    "avg_launch_ms": first[0], "rays_per_launch": first[1], "achieved": first[2],
+                    "frac": first[2] / HBM_PEAK_GBS, "launches": acc["first_launches"]},
                 "algorithmic_bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
                 "triangle_tests_per_ray": tris_per_ray, "timed_launches": acc["timed_launches"] - acc["first_launches"],
                 "note": "Cornell's BVH + triangles are 4 KB and are read from LDS: of the algorithmic bytes only the path "

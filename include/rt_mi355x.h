@@ -274,7 +274,10 @@ int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
  *   HYBRID  bounce 0 (coherent camera rays) by the fused kernel, later bounces (incoherent rays, very uneven
  *           traversal lengths) by extend with per-lane ray refill, then shade
  *   *_LDS   the same with the BVH and primitive tables staged in LDS (only for scenes whose tables fit)
- *   AUTO    FUSED_LDS when the tables fit in 40 KB of LDS, else FUSED (the fastest measured on every scene) */
+ *   PATHS   one kernel launch per batch: every block generates its share of camera rays and then keeps
+ *           bouncing its own survivors (a block only consumes the queue segment it produced, so no grid-wide
+ *           synchronisation is needed between bounces)
+ *   AUTO    PATHS_LDS when the tables fit in 40 KB of LDS, else PATHS (the fastest measured on every scene) */
 enum {
     RT_PIPELINE_AUTO = 0,
     RT_PIPELINE_SPLIT = 1,
@@ -282,7 +285,9 @@ enum {
     RT_PIPELINE_FUSED_LDS = 3,
     RT_PIPELINE_HYBRID = 4,
     RT_PIPELINE_HYBRID_LDS = 5,
-    RT_PIPELINE_SPLIT_LDS = 6
+    RT_PIPELINE_SPLIT_LDS = 6,
+    RT_PIPELINE_PATHS = 7,
+    RT_PIPELINE_PATHS_LDS = 8
 };
 int rt_context_set_pipeline(rt_context *ctx, uint32_t pipeline);
 /* With RT_CTX_TIMING, bracket only the launches of the first `bounces` bounces of every batch with events

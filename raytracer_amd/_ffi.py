@@ -27,7 +27,7 @@ RT_MODE_LINEAR_MEAN, RT_MODE_GAMMA_PER_SAMPLE = 0, 1
 RT_MISS = 0xFFFFFFFF
 RT_CTX_TIMING, RT_CTX_COUNTERS = 1, 2
 (RT_PIPELINE_AUTO, RT_PIPELINE_SPLIT, RT_PIPELINE_FUSED, RT_PIPELINE_FUSED_LDS, RT_PIPELINE_HYBRID,
- RT_PIPELINE_HYBRID_LDS, RT_PIPELINE_SPLIT_LDS) = range(7)
+ RT_PIPELINE_HYBRID_LDS, RT_PIPELINE_SPLIT_LDS, RT_PIPELINE_PATHS, RT_PIPELINE_PATHS_LDS) = range(9)
 
 _f3 = C.c_float * 3
 

@@ -308,7 +308,7 @@ RT_API int rt_context_synchronize(rt_context *c) {
 
 RT_API int rt_context_set_pipeline(rt_context *c, uint32_t pipeline) {
     if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
-    if (pipeline > RT_PIPELINE_SPLIT_LDS) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown pipeline %u", pipeline);
+    if (pipeline > RT_PIPELINE_PATHS_LDS) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown pipeline %u", pipeline);
     c->pipeline = pipeline;
     return RT_OK;
 }
@@ -629,14 +629,16 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // Pipeline choice.  The instrumented extend kernel needs a pipeline that runs extend for every bounce.
     const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
     uint32_t pipeline = c->pipeline;
-    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 40u * 1024u ? RT_PIPELINE_FUSED_LDS : RT_PIPELINE_FUSED;
-    const bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS;
+    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 40u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_PATHS;
+    const bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
+                     pipeline == RT_PIPELINE_PATHS_LDS;
     // Mix materials are evaluated by the split shade kernel only.
     if (count || s->has_mix) pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     if (lds && table_bytes > 64u * 1024u)
         return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
                          (unsigned long long)table_bytes);
-    const bool fused_all = pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
+    const bool paths = pipeline == RT_PIPELINE_PATHS || pipeline == RT_PIPELINE_PATHS_LDS;
+    const bool fused_all = paths || pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
     const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
     const uint32_t lds_bytes = lds ? (uint32_t)table_bytes : 0u;
     c->spans.clear();
@@ -655,7 +657,17 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             rt::launch_generate(c->stream, c->max_blocks, P, ps, n);
             if (int rc = timed_end(c)) return rc;
         }
-        for (uint32_t it = 0; it < st->max_depth; ++it) {
+        if (paths && st->max_depth > 0) { // the whole batch in one launch
+            const size_t rows = (size_t)st->max_depth * grid * sizeof(uint32_t);
+            HIP_TRY(hipMemsetAsync(c->counts.ptr + grid, 0, rows, c->stream));
+            HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
+            if (int rc = timed_begin(c, K_BOUNCE)) return rc;
+            rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr, c->early.ptr,
+                             s->need_uv, lds_bytes);
+            if (int rc = timed_end(c)) return rc;
+            ++bounce_launches;
+        }
+        for (uint32_t it = 0; it < st->max_depth && !paths; ++it) {
             // bounce `it` consumes queue (it-1)&1 with the per-block counts of row `it`, and produces queue it&1
             // with row it+1; bounce 0 consumes the identity queue.
             rt::QueueView q{it == 0 ? nullptr : c->queue[(it - 1) & 1].ptr, c->counts.ptr + (size_t)it * grid, cap, n};
@@ -706,8 +718,11 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
                 // bounce 0 traces every path of the batch
                 const uint64_t r = it == 0 ? (uint64_t)b * npix : c->host_counts[counts_len * bi + it];
                 rays += r;
-                if ((c->flags & RT_CTX_TIMING) && it < c->timed_bounces) {
-                    if (fused_all || (fused_first && it == 0)) {
+                if ((c->flags & RT_CTX_TIMING) && (paths || it < c->timed_bounces)) {
+                    if (paths) { // one timed launch per batch covers every bounce
+                        timed_bounce_rays += r;
+                        if (it == 0) ++timed_bounce;
+                    } else if (fused_all || (fused_first && it == 0)) {
                         timed_bounce_rays += r;
                         ++timed_bounce;
                         if (it == 0) {

@@ -824,6 +824,81 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// paths: every bounce of a batch in ONE launch.  A block only ever consumes the queue segment it produced
+// itself (see QueueView), so the bounce loop needs no grid-wide synchronisation: the block generates its share
+// of camera rays, then keeps bouncing its own survivors between its segments of the two queues until none
+// are left or max_depth is reached.  `counts` / `early` are the [max_depth + 1][gridDim.x] tables the
+// per-bounce kernels fill; rows a block never reaches must have been zeroed by the host.
+// ------------------------------------------------------------------------------------------------------
+template <bool LDS_SCENE, bool NEED_UV>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_paths(
+    SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
+    uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
+    extern __shared__ float4 s_scene[];
+    __shared__ uint32_t s_out, s_early;
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
+    const float4 root_lo = nodes[0], root_hi = nodes[1];
+    if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
+    if (threadIdx.x == 0) {
+        s_out = 0u;
+        s_early = 0u;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t seg = blockIdx.x * cap;
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+
+    // bounce 0: the block's round-robin share of the 256-slot chunks of the batch
+    for (uint32_t off = blockIdx.x * kBlock; off < n_slots; off += gridDim.x * kBlock) {
+        const uint32_t slot = off + threadIdx.x;
+        int alive = kPathEnded;
+        if (slot < n_slots) {
+            V3 o, d;
+            uint32_t s_local, pixel;
+            const uint32_t k = generate_ray(P, slot, o, d, s_local, pixel);
+            Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+            alive = shade_path<NEED_UV, false>(sc, root_lo, root_hi, prims, P, st, slot, o, d, V3{1.0f, 1.0f, 1.0f}, k, 0u, 0u,
+                                               s_local, pixel, best);
+        }
+        compact_survivors(alive, slot, lane, &s_out, &s_early, queue0, seg);
+    }
+    for (uint32_t it = 1;; ++it) {
+        __syncthreads(); // the bounce's appends, and the path state behind them, are complete and visible
+        const uint32_t n_in = s_out;
+        if (threadIdx.x == 0) {
+            counts[(size_t)it * gridDim.x + blockIdx.x] = n_in;
+            early[(size_t)it * gridDim.x + blockIdx.x] = s_early;
+        }
+        if (n_in == 0u || it >= P.max_depth) break;
+        __syncthreads(); // everyone has read the count before it is reset
+        if (threadIdx.x == 0) {
+            s_out = 0u;
+            s_early = 0u;
+        }
+        __syncthreads();
+        const uint32_t *__restrict__ q_in = (it & 1u) ? queue0 : queue1;
+        uint32_t *__restrict__ q_out = (it & 1u) ? queue1 : queue0;
+        for (uint32_t off = 0; off < n_in; off += kBlock) {
+            const uint32_t i = off + threadIdx.x;
+            int alive = kPathEnded;
+            uint32_t slot = 0;
+            if (i < n_in) {
+                slot = q_in[seg + i];
+                const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+                const V3 o = xyz(o4), d = xyz(d4);
+                const uint32_t s_local = f2u(d4.w) >> 16;
+                Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+                alive = shade_path<NEED_UV, false>(sc, root_lo, root_hi, prims, P, st, slot, o, d, xyz(st.beta[slot]),
+                                                   f2u(o4.w) & 0xFFFFFFu, f2u(o4.w) >> 24, f2u(d4.w) & 0xFFFFu, s_local,
+                                                   slot - s_local * P.npix, best);
+            }
+            compact_survivors(alive, slot, lane, &s_out, &s_early, q_out, seg);
+        }
+    }
+}
+
 // Per-bounce ray totals of a batch: totals[it] = sum over blocks of counts[it][b] + early[it][b] (queued rays
 // plus rays whose miss was settled a bounce early).
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ counts,
@@ -968,6 +1043,22 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
         launch_bounce_t<true>(s, grid, sc, P, st, q, queue_out, counts_out, early_out, need_uv, lds_bytes);
     else
         launch_bounce_t<false>(s, grid, sc, P, st, q, queue_out, counts_out, early_out, need_uv, lds_bytes);
+}
+
+void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
+                  uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
+                  uint32_t lds_bytes) {
+    if (lds_bytes) {
+        if (need_uv)
+            hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(kBlock), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+        else
+            hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(kBlock), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+    } else {
+        if (need_uv)
+            hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+        else
+            hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+    }
 }
 
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,

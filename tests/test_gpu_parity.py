@@ -251,14 +251,16 @@ def test_rtiow_spheres_with_defocus_and_background(gpu_ctx):
     assert gst.rays_traced / gst.paths > 1.5
 
 
-LDS_PIPELINES = (F.RT_PIPELINE_FUSED_LDS, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELINE_SPLIT_LDS)
+LDS_PIPELINES = (F.RT_PIPELINE_FUSED_LDS, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELINE_SPLIT_LDS, F.RT_PIPELINE_PATHS_LDS)
 
 
 @pytest.mark.parametrize("pipeline", [F.RT_PIPELINE_SPLIT, F.RT_PIPELINE_FUSED, F.RT_PIPELINE_FUSED_LDS,
-                                      F.RT_PIPELINE_HYBRID, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELINE_SPLIT_LDS])
+                                      F.RT_PIPELINE_HYBRID, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELINE_SPLIT_LDS,
+                                      F.RT_PIPELINE_PATHS, F.RT_PIPELINE_PATHS_LDS])
 def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
-    """Split kernels (generate / extend / shade), the fused per-bounce kernel, the hybrid of the two, each with
-    the scene tables in HBM or staged in LDS, must all give the oracle's sums bit for bit."""
+    """Split kernels (generate / extend / shade), the fused per-bounce kernel, the hybrid of the two and the
+    one-launch-per-batch kernel, each with the scene tables in HBM or staged in LDS, must all give the oracle's
+    sums bit for bit."""
     ctx = Context(0, flags=F.RT_CTX_TIMING)
     ctx.set_pipeline(pipeline)
     cases = [(cornell_with(cornell), None, RenderSettings(120, 90, 0, 50, 6, mode=F.RT_MODE_LINEAR_MEAN, seed=3,

@@ -17,7 +17,7 @@ per_kernel = {}
 for f in glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        if not re.search(r"rt::k_(bounce|extend|shade|generate|accumulate)", name):
+        if not re.search(r"rt::k_(paths|bounce|extend|shade|generate|accumulate)", name):
             continue
         k = re.search(r"rt::(k_[a-z_]+)", name).group(1)
         v = float(row["Counter_Value"])
