@@ -836,7 +836,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
     uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
     extern __shared__ float4 s_scene[];
-    __shared__ uint32_t s_out, s_early;
+    __shared__ uint32_t s_out, s_early, s_next;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = nodes[0], root_hi = nodes[1];
@@ -844,15 +844,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
     if (threadIdx.x == 0) {
         s_out = 0u;
         s_early = 0u;
+        s_next = 0u;
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t seg = blockIdx.x * cap;
     uint32_t c0 = 0, c1 = 0, c2 = 0;
 
-    // bounce 0: the block's round-robin share of the 256-slot chunks of the batch
-    for (uint32_t off = blockIdx.x * kBlock; off < n_slots; off += gridDim.x * kBlock) {
-        const uint32_t slot = off + threadIdx.x;
+    // Within a bounce the block's waves claim 64 items at a time from a shared cursor, so a wave that drew
+    // long traversals does not leave the others waiting at the end of the bounce.
+    //
+    // bounce 0: the block's round-robin share of the 256-slot chunks of the batch, in quarter chunks
+    const uint32_t chunks = (n_slots + kBlock - 1) / kBlock;
+    const uint32_t my_quarters = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * 4u : 0u;
+    for (;;) {
+        uint32_t quarter = 0;
+        if (lane == 0) quarter = atomicAdd(&s_next, 1u);
+        quarter = __shfl(quarter, 0);
+        if (quarter >= my_quarters) break;
+        const uint32_t slot = ((quarter >> 2) * gridDim.x + blockIdx.x) * kBlock + (quarter & 3u) * 64u + lane;
         int alive = kPathEnded;
         if (slot < n_slots) {
             V3 o, d;
@@ -876,12 +886,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
         if (threadIdx.x == 0) {
             s_out = 0u;
             s_early = 0u;
+            s_next = 0u;
         }
         __syncthreads();
         const uint32_t *__restrict__ q_in = (it & 1u) ? queue0 : queue1;
         uint32_t *__restrict__ q_out = (it & 1u) ? queue1 : queue0;
-        for (uint32_t off = 0; off < n_in; off += kBlock) {
-            const uint32_t i = off + threadIdx.x;
+        for (;;) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, 64u);
+            base = __shfl(base, 0);
+            if (base >= n_in) break;
+            const uint32_t i = base + lane;
             int alive = kPathEnded;
             uint32_t slot = 0;
             if (i < n_in) {
