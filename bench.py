@@ -26,7 +26,7 @@ import torch
 
 WIDTH, HEIGHT, MAX_DEPTH, SEED = 1920, 1080, 50, 1  # --width / --height override the size for rehearsals only
 SPP_PER_STEP = 64
-MAX_PATHS = 1 << 26          # path slots per batch: 32 samples of a 1080p frame
+MAX_PATHS = 1 << 27          # path slots per batch: the 64 samples of a 1080p frame a step renders (11.8 GB of state)
 TIMED_BOUNCES = 6            # extend launches bracketed by HIP events per batch (they carry > 98 % of the rays)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 
@@ -221,8 +221,8 @@ def main():
         avg_launch_ms, rays_per_launch, achieved = later
         one_launch_per_batch = acc["pipeline"] in (F.RT_PIPELINE_PATHS, F.RT_PIPELINE_PATHS_LDS)
         if one_launch_per_batch:
-            kernel_name = ("k_paths<true,false> (one launch per batch of 32 spp: generate + extend + shade of every bounce; "
-                           "BVH and triangles staged in LDS)")
+            kernel_name = ("k_paths<true,false> (one launch per batch of %d spp: generate + extend + shade of every bounce; "
+                           "BVH and triangles staged in LDS)" % min(spp, MAX_PATHS // npix))
         else:
             kernel_name = ("k_bounce<false,true,false> (extend + shade of bounces 1..%d of each batch, BVH and triangles "
                            "staged in LDS)" % (TIMED_BOUNCES - 1))

@@ -266,7 +266,9 @@ int rt_context_create(int device, void *stream, uint32_t flags, rt_context **out
 int rt_context_destroy(rt_context *ctx);
 /* Blocks until all work queued on the context's stream has finished. */
 int rt_context_synchronize(rt_context *ctx);
-/* Upper bound on concurrently traced paths (slots of wavefront state).  0 restores the default. */
+/* Upper bound on concurrently traced paths (slots of wavefront state, 88 bytes of HBM each).  A render call is
+ * cut into batches of at most this many paths; larger batches mean fewer kernel launches.  0 restores the
+ * default (2^26). */
 int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
 /* Which kernels render a batch.  All pipelines produce bit-identical sums.
  *   SPLIT   generate, then per bounce extend + shade (the hit record travels through HBM)

@@ -91,7 +91,7 @@ struct rt_context {
     uint32_t max_blocks = 2048;       // grid of the helper kernels: 8 blocks per CU
     uint32_t cus = 256;
     uint32_t blocks_per_cu = 0;       // render grid, blocks per CU; 0 = chosen per scene (see rt_render_device)
-    uint64_t max_paths = 1ull << 24;
+    uint64_t max_paths = 1ull << 26;
     uint32_t timed_bounces = 0xFFFFFFFFu;
     uint32_t pipeline = RT_PIPELINE_AUTO;
 
@@ -323,7 +323,7 @@ RT_API int rt_context_set_timed_bounces(rt_context *c, uint32_t bounces) {
 
 RT_API int rt_context_set_max_paths(rt_context *c, uint64_t max_paths) {
     if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
-    c->max_paths = max_paths ? max_paths : (1ull << 24);
+    c->max_paths = max_paths ? max_paths : (1ull << 26);
     return RT_OK;
 }
 

@@ -51,13 +51,34 @@ __device__ __forceinline__ bool box_hit(float4 nlo, float4 nhi, V3 o, V3 inv, fl
 // of the packed binary32 subtract and multiply; operations and their order per lane are unchanged.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// v_max_f32 / v_min_f32 as the hardware does them (the other operand when one is a NaN).  fmaxf / fminf compile to
+// the same instruction preceded by a quieting `v_max x, x` whenever the compiler cannot prove an operand is not a
+// signalling NaN, which it cannot for the loop-carried closest distance; that extra instruction changes nothing.
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// A copy of `x` that lives in a vector register (so that a loop-invariant scalar is not moved there anew in
+// every iteration in front of max_raw).
+__device__ __forceinline__ float in_vgpr(float x) {
+    float r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ bool box_hit_pairs(float4 a, float4 b, V3 o, V3 inv, float lo, float hi) {
     v2f tx = (v2f{a.x, a.y} - v2f{o.x, o.x}) * v2f{inv.x, inv.x};
     v2f ty = (v2f{a.z, a.w} - v2f{o.y, o.y}) * v2f{inv.y, inv.y};
     v2f tz = (v2f{b.x, b.y} - v2f{o.z, o.z}) * v2f{inv.z, inv.z};
     bool s = tx.x < tx.y;
-    lo = fmaxf(lo, s ? tx.x : tx.y);
-    hi = fminf(hi, s ? tx.y : tx.x);
+    lo = max_raw(lo, s ? tx.x : tx.y);
+    hi = min_raw(hi, s ? tx.y : tx.x);
     s = ty.x < ty.y;
     lo = fmaxf(lo, s ? ty.x : ty.y);
     hi = fminf(hi, s ? ty.y : ty.x);
@@ -130,11 +151,16 @@ __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, co
                                             uint32_t &n_nodes_visited, uint32_t &n_tri, uint32_t &n_sph) {
     V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    // With PAIRS the walk runs on byte offsets into the LDS copy (32 per node; the copy's skip links are
+    // stored that way), which is the address the LDS read wants.
+    constexpr uint32_t kStep = PAIRS ? 32u : 1u;
+    if (PAIRS) tmin = in_vgpr(tmin);
     uint32_t idx = 0;
-    const uint32_t end = n_nodes;
+    const uint32_t end = n_nodes * kStep;
     while (idx < end) {
-        float4 nlo = nodes[2 * idx];
-        float4 nhi = nodes[2 * idx + 1];
+        const float4 *node = PAIRS ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + idx) : nodes + 2 * idx;
+        float4 nlo = node[0];
+        float4 nhi = node[1];
         if (COUNT) ++n_nodes_visited;
         bool hit = PAIRS ? box_hit_pairs(nlo, nhi, o, inv, tmin, best.t) : box_hit(nlo, nhi, o, inv, tmin, best.t);
         uint32_t leaf = f2u(nhi.w);
@@ -148,7 +174,7 @@ __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, co
                 tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
             }
         }
-        idx = hit ? idx + 1 : f2u(PAIRS ? nhi.z : nlo.w);
+        idx = hit ? idx + kStep : f2u(PAIRS ? nhi.z : nlo.w);
     }
     return best;
 }
@@ -500,7 +526,7 @@ __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *l
     for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += kBlock) { // into the paired layout of box_hit_pairs
         const float4 lo = nodes[2 * i], hi = nodes[2 * i + 1];
         lds[2 * i] = make_float4(lo.x, hi.x, lo.y, hi.y);
-        lds[2 * i + 1] = make_float4(lo.z, hi.z, lo.w, hi.w);
+        lds[2 * i + 1] = make_float4(lo.z, hi.z, u2f(f2u(lo.w) * 32u), hi.w); // skip as a byte offset
     }
     for (uint32_t i = threadIdx.x; i < n4_prims; i += kBlock) lds[n4_nodes + i] = prims[i];
     nodes = lds;
@@ -589,6 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
             // one step of BvhNode::hit's pre-order walk (see traverse())
             float4 nlo = nodes[2 * idx];
             float4 nhi = nodes[2 * idx + 1];
+            if (LDS_SCENE) nhi.z = u2f(f2u(nhi.z) >> 5); // the LDS copy stores skip links as byte offsets
             if (COUNT) ++c_nodes;
             bool hit = LDS_SCENE ? box_hit_pairs(nlo, nhi, o, inv, tmin, best.t) : box_hit(nlo, nhi, o, inv, tmin, best.t);
             uint32_t leaf = f2u(nhi.w);
