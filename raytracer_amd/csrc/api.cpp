@@ -403,8 +403,7 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
     s->info.num_spheres = hs.n_spheres;
     s->info.num_nodes = s->dev.n_nodes;
     s->info.depth = hs.depth;
-    std::memcpy(s->info.bounds_min, root.bmin, 12);
-    std::memcpy(s->info.bounds_max, root.bmax, 12);
+    root.get_box(s->info.bounds_min, s->info.bounds_max);
     s->info.device_bytes = bytes;
     *out = s;
     return RT_OK;
@@ -431,8 +430,7 @@ RT_API int rt_scene_export_bvh(const rt_scene *s, float *boxes, int32_t *leaf_pr
     std::vector<rt::Node> nodes(s->dev.n_nodes);
     HIP_TRY(hipMemcpy(nodes.data(), s->dev.nodes, nodes.size() * sizeof(rt::Node), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nodes.size(); ++i) {
-        std::memcpy(boxes + 6 * i, nodes[i].bmin, 12);
-        std::memcpy(boxes + 6 * i + 3, nodes[i].bmax, 12);
+        nodes[i].get_box(boxes + 6 * i, boxes + 6 * i + 3);
         skip[i] = nodes[i].skip;
         leaf_prim[i] = nodes[i].leaf == rt::kInterior ? -1 : (int32_t)s->prim_of_slot[nodes[i].leaf & ~rt::kSphereBit];
     }

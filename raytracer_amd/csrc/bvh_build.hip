@@ -79,8 +79,8 @@ __device__ __forceinline__ int longest_axis(const DBox &b) { // x is only ever c
 
 __device__ __forceinline__ void write_node(Node *nodes, uint32_t at, const DBox &b, uint32_t skip, uint32_t leaf) {
     float4 *out = reinterpret_cast<float4 *>(nodes + at);
-    out[0] = make_float4(b.lo[0], b.lo[1], b.lo[2], __uint_as_float(skip));
-    out[1] = make_float4(b.hi[0], b.hi[1], b.hi[2], __uint_as_float(leaf));
+    out[0] = make_float4(b.lo[0], b.hi[0], b.lo[1], b.hi[1]);
+    out[1] = make_float4(b.lo[2], b.hi[2], __uint_as_float(skip), __uint_as_float(leaf));
 }
 
 // Ascending unsigned order of this value == the host comparator's order (descending key, NaN first, -0 == +0).

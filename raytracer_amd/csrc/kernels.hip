@@ -22,33 +22,13 @@ __device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v
 // intersection
 // ------------------------------------------------------------------------------------------------------
 
-// Aabb::hit (src/aabb.rs:95-127).  The reference recomputes 1/d per node; the value is the same every time,
-// so it is computed once per ray.  Per axis it orders (t0, t1) with `t0 < t1` and then narrows [lo, hi] by
-// compare-and-assign, which leaves the interval untouched by a NaN; fmaxf/fminf have exactly that
-// behaviour because lo and hi themselves are never NaN.  The per-axis early `max <= min` exits are
-// equivalent to one test at the end because the interval only ever shrinks.
-__device__ __forceinline__ bool box_hit(float4 nlo, float4 nhi, V3 o, V3 inv, float lo, float hi) {
-    float t0 = (nlo.x - o.x) * inv.x;
-    float t1 = (nhi.x - o.x) * inv.x;
-    bool s = t0 < t1;
-    lo = fmaxf(lo, s ? t0 : t1);
-    hi = fminf(hi, s ? t1 : t0);
-    t0 = (nlo.y - o.y) * inv.y;
-    t1 = (nhi.y - o.y) * inv.y;
-    s = t0 < t1;
-    lo = fmaxf(lo, s ? t0 : t1);
-    hi = fminf(hi, s ? t1 : t0);
-    t0 = (nlo.z - o.z) * inv.z;
-    t1 = (nhi.z - o.z) * inv.z;
-    s = t0 < t1;
-    lo = fmaxf(lo, s ? t0 : t1);
-    hi = fminf(hi, s ? t1 : t0);
-    return !(hi <= lo);
-}
-
-// The same test on a node stored as (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, skip, leaf) — the layout of the LDS
-// copy of the node table.  The two planes of an axis then sit in one register pair, which is the operand shape
-// of the packed binary32 subtract and multiply; operations and their order per lane are unchanged.
+// Aabb::hit (src/aabb.rs:95-127) on a node stored as (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, skip, leaf).  The
+// reference recomputes 1/d per node; the value is the same every time, so it is computed once per ray.  Per
+// axis it orders (t0, t1) with `t0 < t1` and then narrows [lo, hi] by compare-and-assign, which leaves the
+// interval untouched by a NaN; v_max_f32 / v_min_f32 have exactly that behaviour because lo and hi themselves
+// are never NaN.  The per-axis early `max <= min` exits are equivalent to one test at the end because the
+// interval only ever shrinks.  The two planes of an axis sit in one register pair, the operand shape of the
+// packed binary32 subtract and multiply; operations and their order per lane are the reference's.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // v_max_f32 / v_min_f32 as the hardware does them (the other operand when one is a NaN).  fmaxf / fminf compile to
@@ -72,7 +52,7 @@ __device__ __forceinline__ float min_raw(float a, float b) {
     return r;
 }
 
-__device__ __forceinline__ bool box_hit_pairs(float4 a, float4 b, V3 o, V3 inv, float lo, float hi) {
+__device__ __forceinline__ bool box_hit(float4 a, float4 b, V3 o, V3 inv, float lo, float hi) {
     v2f tx = (v2f{a.x, a.y} - v2f{o.x, o.x}) * v2f{inv.x, inv.x};
     v2f ty = (v2f{a.z, a.w} - v2f{o.y, o.y}) * v2f{inv.y, inv.y};
     v2f tz = (v2f{b.x, b.y} - v2f{o.z, o.z}) * v2f{inv.z, inv.z};
@@ -144,25 +124,25 @@ __device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uin
 // shrinking `hit_range.max`: the reference hands the right sibling max = the left hit's distance, and every
 // later node therefore sees the closest distance found so far in visiting order.
 // `nodes` / `prims` may point at HBM or at a copy of the tables in LDS.
-// PAIRS: `nodes` is the LDS copy in the paired layout of box_hit_pairs.
-template <bool COUNT, bool PAIRS>
+// LDS: `nodes` is the LDS copy, whose skip links are byte offsets.
+template <bool COUNT, bool LDS>
 __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ prims,
                                             uint32_t n_nodes, V3 o, V3 d, float tmin, float tmax,
                                             uint32_t &n_nodes_visited, uint32_t &n_tri, uint32_t &n_sph) {
     V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
-    // With PAIRS the walk runs on byte offsets into the LDS copy (32 per node; the copy's skip links are
-    // stored that way), which is the address the LDS read wants.
-    constexpr uint32_t kStep = PAIRS ? 32u : 1u;
-    if (PAIRS) tmin = in_vgpr(tmin);
+    // On the LDS copy the walk runs on byte offsets (32 per node; the copy's skip links are stored that way),
+    // which is the address the LDS read wants.
+    constexpr uint32_t kStep = LDS ? 32u : 1u;
+    tmin = in_vgpr(tmin);
     uint32_t idx = 0;
     const uint32_t end = n_nodes * kStep;
     while (idx < end) {
-        const float4 *node = PAIRS ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + idx) : nodes + 2 * idx;
+        const float4 *node = LDS ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + idx) : nodes + 2 * idx;
         float4 nlo = node[0];
         float4 nhi = node[1];
         if (COUNT) ++n_nodes_visited;
-        bool hit = PAIRS ? box_hit_pairs(nlo, nhi, o, inv, tmin, best.t) : box_hit(nlo, nhi, o, inv, tmin, best.t);
+        bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
         uint32_t leaf = f2u(nhi.w);
         if (hit && leaf != kInterior) {
             uint32_t slot = leaf & ~kSphereBit;
@@ -174,7 +154,7 @@ __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, co
                 tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
             }
         }
-        idx = hit ? idx + kStep : f2u(PAIRS ? nhi.z : nlo.w);
+        idx = hit ? idx + kStep : f2u(nhi.z);
     }
     return best;
 }
@@ -523,10 +503,11 @@ __device__ __forceinline__ QueueCursor queue_begin(const QueueView &q) {
 __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *lds, const float4 *&nodes,
                                                    const float4 *&prims) {
     const uint32_t n4_nodes = 2u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
-    for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += kBlock) { // into the paired layout of box_hit_pairs
-        const float4 lo = nodes[2 * i], hi = nodes[2 * i + 1];
-        lds[2 * i] = make_float4(lo.x, hi.x, lo.y, hi.y);
-        lds[2 * i + 1] = make_float4(lo.z, hi.z, u2f(f2u(lo.w) * 32u), hi.w); // skip as a byte offset
+    for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += kBlock) {
+        float4 second = nodes[2 * i + 1];
+        second.z = u2f(f2u(second.z) * 32u); // skip as a byte offset
+        lds[2 * i] = nodes[2 * i];
+        lds[2 * i + 1] = second;
     }
     for (uint32_t i = threadIdx.x; i < n4_prims; i += kBlock) lds[n4_nodes + i] = prims[i];
     nodes = lds;
@@ -617,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
             float4 nhi = nodes[2 * idx + 1];
             if (LDS_SCENE) nhi.z = u2f(f2u(nhi.z) >> 5); // the LDS copy stores skip links as byte offsets
             if (COUNT) ++c_nodes;
-            bool hit = LDS_SCENE ? box_hit_pairs(nlo, nhi, o, inv, tmin, best.t) : box_hit(nlo, nhi, o, inv, tmin, best.t);
+            bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
             uint32_t leaf = f2u(nhi.w);
             if (hit && leaf != kInterior) {
                 uint32_t ps = leaf & ~kSphereBit;
@@ -629,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
                     tri_test(prims + 3 * (size_t)ps, ps, o, d, tmin, best);
                 }
             }
-            idx = hit ? idx + 1 : f2u(LDS_SCENE ? nhi.z : nlo.w);
+            idx = hit ? idx + 1 : f2u(nhi.z);
             if (idx >= end) {
                 hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
                 have = false;

@@ -14,11 +14,19 @@ constexpr uint32_t kMissSlot = 0xFFFFFFFFu;
 // BvhNode::hit visits them, src/bvh.rs:295-317): the left child of node i is node i + 1 and `skip` is the
 // node that follows i's whole subtree, so "box hit -> i + 1, box miss -> skip" walks the tree in exactly the
 // reference's always-left-first order without a stack.  A leaf's `skip` is i + 1.
+// The two planes of an axis are neighbours so that a 16-byte load puts them in one register pair, the operand
+// shape of the packed binary32 subtract and multiply of the slab test.
 struct alignas(16) Node {
-    float bmin[3];
+    float xlo, xhi, ylo, yhi; // first 16 bytes
+    float zlo, zhi;
     uint32_t skip;
-    float bmax[3];
     uint32_t leaf; // kInterior, or index into the leaf-ordered primitive table (| kSphereBit)
+    void set_box(const float lo[3], const float hi[3]) {
+        xlo = lo[0], xhi = hi[0], ylo = lo[1], yhi = hi[1], zlo = lo[2], zhi = hi[2];
+    }
+    void get_box(float lo[3], float hi[3]) const {
+        lo[0] = xlo, lo[1] = ylo, lo[2] = zlo, hi[0] = xhi, hi[1] = yhi, hi[2] = zhi;
+    }
 };
 static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 

@@ -125,8 +125,7 @@ struct Builder {
         Node &n = nodes[at];
         if (len == 1) {
             const Box &b = obj_boxes[order[lo]];
-            std::memcpy(n.bmin, b.lo, sizeof n.bmin);
-            std::memcpy(n.bmax, b.hi, sizeof n.bmax);
+            n.set_box(b.lo, b.hi);
             n.skip = at + 1;
             n.leaf = lo; // slot in the leaf-ordered tables; the sphere bit is added by the caller
             return;
@@ -139,8 +138,7 @@ struct Builder {
         std::sort(items.begin(), items.end(), sort_before);
         for (uint32_t i = 0; i < len; ++i) order[lo + i] = items[i].id;
         std::vector<SortItem>().swap(items);
-        std::memcpy(n.bmin, bbox.lo, sizeof n.bmin);
-        std::memcpy(n.bmax, bbox.hi, sizeof n.bmax);
+        n.set_box(bbox.lo, bbox.hi);
         n.skip = at + 2 * len - 1;
         n.leaf = kInterior;
         const uint32_t mid = len / 2;
