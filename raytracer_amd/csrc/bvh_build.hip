@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void k_nodes_long(Level lv, const uint32_
     __shared__ DBox s_prefix;
     DBox acc = empty_box();
     for (uint32_t k = threadIdx.x; k < len; k += kThreads) union_plain(acc, lv.boxes[lv.order[p + k]]);
-    // min / max over the block: wave shuffles, then the first wave over the per-wave results
+    // min / max over the block: wave shuffles, then thread 0 over the per-wave results
     float v[6] = {acc.lo[0], acc.lo[1], acc.lo[2], acc.hi[0], acc.hi[1], acc.hi[2]};
     for (int sh = 32; sh > 0; sh >>= 1)
         for (int c = 0; c < 6; ++c) {

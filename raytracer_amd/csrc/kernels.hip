@@ -1,8 +1,9 @@
-// kernels.hip — the wavefront path tracer for gfx950: generate / extend / shade / accumulate.
+// kernels.hip — the wavefront path tracer for gfx950: generate / extend / shade / accumulate, the per-bounce
+// fusion of the first three (k_bounce) and the whole bounce loop of a batch in one launch (k_paths).
 //
-// Every kernel is a grid-stride loop over a queue of path slots whose length lives in device memory, so the
-// host never has to read a count back between bounces.  One lane owns one path.  All arithmetic is binary32
-// in the reference's operation order (built with -ffp-contract=off), including its inf/NaN behaviour.
+// Every kernel loops over a queue of path slots whose length lives in device memory, so the host never has to
+// read a count back between bounces.  One lane owns one path.  All arithmetic is binary32 in the reference's
+// operation order (built with -ffp-contract=off), including its inf/NaN behaviour.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
