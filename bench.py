@@ -206,6 +206,29 @@ def main():
             if kern:
                 traffic_per_ray = kern["hbm_read_bytes_per_ray"] + kern["hbm_write_bytes_per_ray"]
 
+        # VALU picture of the same kernel from the committed PMC run (the kernel is instruction-issue bound, which the
+        # HBM roofline above cannot show): wave-level VALU instructions per ray, VALU-busy share of SIMD cycles
+        # (4 cycles per wave64 instruction, 1024 SIMDs, GRBM_GUI_ACTIVE summed over the 8 XCDs) and lane utilisation.
+        valu = None
+        pj = os.path.join(ROOT, "profiles", "r01_v6_pmc_summary_cornell1080p_paths_lds.txt")
+        if os.path.exists(pj) and os.path.exists(tj):
+            vals, on = {}, False
+            for line in open(pj):
+                if not line.startswith(" "):
+                    on = "k_paths" in line
+                elif on:
+                    parts = line.split()
+                    vals[parts[0]] = float(parts[1])
+            pmc_rays = json.load(open(tj)).get("rays", 0)
+            if pmc_rays and "SQ_INSTS_VALU" in vals:
+                simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+                valu = {"wave_instructions_per_ray": vals["SQ_INSTS_VALU"] / pmc_rays,
+                        "busy_share_of_simd_cycles": 4.0 * vals["SQ_ACTIVE_INST_VALU"] / simd_cycles,
+                        "lane_utilisation": vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_INSTS_VALU"]),
+                        "source": "profiles/r01_v6_pmc_summary_cornell1080p_paths_lds.txt (PMC, not measured in this run; "
+                                  "the busy share divides counters of two profiling passes and reads slightly above 1 when "
+                                  "the VALUs are saturated)"}
+
         # The fused kernel has two instances: k_bounce<FIRST=true> (bounce 0: camera rays generated in place) and
         # k_bounce<FIRST=false> (later bounces).  Later bounces dominate the time; bounces 1..TIMED_BOUNCES-1 of every
         # batch are bracketed by events here, bounce 0 separately.
@@ -265,6 +288,7 @@ def main():
                     "kernel": "k_bounce<true,true,false> (generate + extend + shade of bounce 0)",
                     "avg_launch_ms": first[0], "rays_per_launch": first[1], "achieved": first[2],
                     "frac": first[2] / HBM_PEAK_GBS, "launches": acc["first_launches"]},
+                "valu": valu,
                 "algorithmic_bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
                 "triangle_tests_per_ray": tris_per_ray, "timed_launches": acc["timed_launches"] - acc["first_launches"],
                 "note": "Cornell's BVH + triangles are 4 KB and are read from LDS: of the algorithmic bytes only the path "
