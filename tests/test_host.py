@@ -359,3 +359,20 @@ def test_png_base_colour_textures(tmp_path):
     assert b"JPEG" in lib.rt_last_error()
     broken = cases[0][1][:-40]
     assert lib.rt_gltf_load(os.fsencode(_textured_gltf(tmp_path, "broken", broken, "uri")), C.byref(handle)) == F.RT_ERR_PARSE
+
+
+def test_rust_binding_declares_every_entry_point():
+    """The `-sys` crate source (bindings/rust, uncompiled: no Rust toolchain here) must stay in step with the
+    header: same set of functions, same field order in every struct."""
+    header = open(os.path.join(ROOT, "include", "rt_mi355x.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    rust = open(os.path.join(ROOT, "bindings", "rust", "rt-mi355x-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", header))
+    bound = set(re.findall(r"pub fn (rt_[a-z_0-9]+)\s*\(", rust))
+    assert declared == bound, declared ^ bound
+    for name, body in re.findall(r"typedef struct (rt_[a-z_]+) \{(.*?)\} \1;", header, flags=re.S):
+        c_fields = re.findall(r"([a-z_0-9]+)(?:\[\d+\])?;", body)
+        m = re.search(r"pub struct %s \{(.*?)\n\}" % name, rust, flags=re.S)
+        assert m, f"{name} missing from the Rust binding"
+        rust_fields = re.findall(r"pub ([a-z_0-9]+):", m.group(1))
+        assert c_fields == rust_fields, (name, c_fields, rust_fields)
