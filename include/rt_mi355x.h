@@ -279,7 +279,9 @@ int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
  *   PATHS   one kernel launch per batch: every block generates its share of camera rays and then keeps
  *           bouncing its own survivors (a block only consumes the queue segment it produced, so no grid-wide
  *           synchronisation is needed between bounces)
- *   AUTO    PATHS_LDS when the tables fit in 40 KB of LDS, else PATHS (the fastest measured on every scene) */
+ *   AUTO    PATHS_LDS when the tables fit in 150 KB of LDS (256-thread blocks up to 40 KB, above that one
+ *           1024-thread block per CU shares the copy), else PATHS: the fastest measured on every scene.  The other
+ *           *_LDS pipelines take tables up to 64 KB. */
 enum {
     RT_PIPELINE_AUTO = 0,
     RT_PIPELINE_SPLIT = 1,

@@ -595,14 +595,35 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const uint32_t B = (uint32_t)per_batch;
     const size_t slots = (size_t)B * npix;
     if (slots > 0x7FFFFFFFull) return set_error(RT_ERR_INVALID_ARGUMENT, "batch exceeds 2^31 paths");
+    const bool count = stats && (c->flags & RT_CTX_COUNTERS);
+    // Pipeline choice.  The instrumented extend kernel needs a pipeline that runs extend for every bounce.
+    const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
+    uint32_t pipeline = c->pipeline;
+    // AUTO: tables up to 40 KB go to LDS once per 256-thread block; up to 150 KB once per 1024-thread block, one
+    // block per CU (485 spheres, 54 KB: 12.4 vs 8.8 Grays/s from L1/L2); larger scenes are read through the caches.
+    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_PATHS;
+    bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
+               pipeline == RT_PIPELINE_PATHS_LDS;
+    // Mix materials are evaluated by the split shade kernel only.
+    if (count || s->has_mix) {
+        if (c->pipeline == RT_PIPELINE_AUTO && table_bytes > 64u * 1024u) lds = false;
+        pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
+    }
+    const bool big_blocks = pipeline == RT_PIPELINE_PATHS_LDS && table_bytes > 40u * 1024u;
+    if (lds && table_bytes > (big_blocks ? 150u : 64u) * 1024u)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
+                         (unsigned long long)table_bytes);
+    const bool paths = pipeline == RT_PIPELINE_PATHS || pipeline == RT_PIPELINE_PATHS_LDS;
+    const bool fused_all = paths || pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
+    const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
+    const uint32_t lds_bytes = lds ? (uint32_t)table_bytes : 0u;
     // One grid for every bounce of a batch: block b owns segment b of both queues (see QueueView).
     const uint32_t chunks = (uint32_t)((slots + 255) / 256);
     // A CU holds six of these 256-thread blocks (six waves per SIMD) and whole rounds of six run best.  Scenes
     // whose tables stay in LDS or L1/L2 like many small blocks (four rounds: short tails); scenes read from HBM
     // like one round of large blocks (fewer part-filled waves in the late bounces).  Measured: Cornell 24.6 vs
     // 21.9 Grays/s, 485 spheres 7.9 vs 7.6, teapot 3.65 vs 3.88, 10 M soup 0.217 vs 0.276 (24 vs 6 blocks per CU).
-    const uint64_t scene_table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
-    const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu : (scene_table_bytes <= 256u * 1024u ? 24u : 6u);
+    const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu : big_blocks ? 1u : (table_bytes <= 256u * 1024u ? 24u : 6u);
     const uint32_t grid = std::min(c->cus * blocks_per_cu, chunks);
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
     if (int rc = ensure_render(c, slots, (size_t)grid * cap, st->max_depth, grid)) return rc;
@@ -630,23 +651,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     P.seed_mix = rt::mix64(st->seed);
 
     rt::PathState ps{c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, c->beta.ptr, c->radiance.ptr};
-    const bool count = stats && (c->flags & RT_CTX_COUNTERS);
     if (count) HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(rt::ExtendCounters), c->stream));
-    // Pipeline choice.  The instrumented extend kernel needs a pipeline that runs extend for every bounce.
-    const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
-    uint32_t pipeline = c->pipeline;
-    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 40u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_PATHS;
-    const bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
-                     pipeline == RT_PIPELINE_PATHS_LDS;
-    // Mix materials are evaluated by the split shade kernel only.
-    if (count || s->has_mix) pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
-    if (lds && table_bytes > 64u * 1024u)
-        return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
-                         (unsigned long long)table_bytes);
-    const bool paths = pipeline == RT_PIPELINE_PATHS || pipeline == RT_PIPELINE_PATHS_LDS;
-    const bool fused_all = paths || pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
-    const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
-    const uint32_t lds_bytes = lds ? (uint32_t)table_bytes : 0u;
     c->spans.clear();
     c->ev_used = 0;
     if (stats) HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
@@ -669,7 +674,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr, c->early.ptr,
-                             s->need_uv, lds_bytes);
+                             s->need_uv, lds_bytes, big_blocks);
             if (int rc = timed_end(c)) return rc;
             ++bounce_launches;
         }

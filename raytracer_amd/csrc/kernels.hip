@@ -504,13 +504,13 @@ __device__ __forceinline__ QueueCursor queue_begin(const QueueView &q) {
 __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *lds, const float4 *&nodes,
                                                    const float4 *&prims) {
     const uint32_t n4_nodes = 2u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
-    for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += kBlock) {
+    for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += blockDim.x) {
         float4 second = nodes[2 * i + 1];
         second.z = u2f(f2u(second.z) * 32u); // skip as a byte offset
         lds[2 * i] = nodes[2 * i];
         lds[2 * i + 1] = second;
     }
-    for (uint32_t i = threadIdx.x; i < n4_prims; i += kBlock) lds[n4_nodes + i] = prims[i];
+    for (uint32_t i = threadIdx.x; i < n4_prims; i += blockDim.x) lds[n4_nodes + i] = prims[i];
     nodes = lds;
     prims = lds + n4_nodes;
 }
@@ -840,8 +840,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
 // are left or max_depth is reached.  `counts` / `early` are the [max_depth + 1][gridDim.x] tables the
 // per-bounce kernels fill; rows a block never reaches must have been zeroed by the host.
 // ------------------------------------------------------------------------------------------------------
-template <bool LDS_SCENE, bool NEED_UV>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_paths(
+// THREADS: 256, or 1024 for scenes whose tables take a large part of a CU's LDS (one copy then serves sixteen
+// waves instead of four); work is claimed per wave, so nothing else depends on the block size.
+template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == kBlock ? 6 : 4))) void k_paths(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
     uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
     extern __shared__ float4 s_scene[];
@@ -1071,8 +1073,13 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  uint32_t lds_bytes) {
-    if (lds_bytes) {
+                  uint32_t lds_bytes, bool big_blocks) {
+    if (lds_bytes && big_blocks) {
+        auto kernel = need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
+        if (lds_bytes > 48u * 1024u)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+    } else if (lds_bytes) {
         if (need_uv)
             hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(kBlock), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
         else
