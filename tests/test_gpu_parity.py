@@ -286,6 +286,16 @@ def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
     ctx.close()
 
 
+def test_mid_size_scene_uses_the_shared_lds_copy(gpu_ctx):
+    """Scene tables between 40 and 150 KB (here 1200 triangles = 134 KB, and the 485 spheres = 54 KB) are staged
+    in LDS once per 1024-thread block by the default pipeline; sums and ray counts equal the oracle's."""
+    for desc, cs, bg in ((triangle_soup(1200, emissive_fraction=0.05) + ((0.3, 0.4, 0.5),)), (rtiow_final_scene() + ((0.7, 0.8, 1.0),))):
+        rs = RenderSettings(200, 120, 0, 20, 5, mode=F.RT_MODE_LINEAR_MEAN, seed=8, background_color=bg)
+        gpu, cpu, gst, cst = render_pair(gpu_ctx, desc, cs, rs)
+        assert_images_equal(gpu, cpu)
+        assert gst.rays_traced == cst.rays_traced and gst.pipeline == F.RT_PIPELINE_PATHS_LDS
+
+
 def test_mix_materials(gpu_ctx, cornell):
     """Mix (src/material.rs:186-204): blended attenuation, one extra draw to pick the ray, children that do
     not scatter (a light), the factor 0 / 1 shortcuts and nesting four deep."""
