@@ -623,7 +623,13 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // whose tables stay in LDS or L1/L2 like many small blocks (four rounds: short tails); scenes read from HBM
     // like one round of large blocks (fewer part-filled waves in the late bounces).  Measured: Cornell 24.6 vs
     // 21.9 Grays/s, 485 spheres 7.9 vs 7.6, teapot 3.65 vs 3.88, 10 M soup 0.217 vs 0.276 (24 vs 6 blocks per CU).
-    const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu : big_blocks ? 1u : (table_bytes <= 256u * 1024u ? 24u : 6u);
+    // Tables beyond what the L2s hold are read from HBM: eight waves per SIMD (and eight blocks per CU) hide more
+    // of that latency than six; 10 M soup 0.286 -> 0.325 Grays/s, while the L2-resident teapot loses 2 % with them.
+    const bool eight_waves = pipeline == RT_PIPELINE_PATHS && table_bytes > (16u << 20);
+    const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu
+                                   : big_blocks    ? 1u
+                                   : eight_waves   ? 8u
+                                                   : (table_bytes <= 256u * 1024u ? 24u : 6u);
     const uint32_t grid = std::min(c->cus * blocks_per_cu, chunks);
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
     if (int rc = ensure_render(c, slots, (size_t)grid * cap, st->max_depth, grid)) return rc;
@@ -674,7 +680,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr, c->early.ptr,
-                             s->need_uv, lds_bytes, big_blocks);
+                             s->need_uv, lds_bytes, big_blocks, eight_waves);
             if (int rc = timed_end(c)) return rc;
             ++bounce_launches;
         }

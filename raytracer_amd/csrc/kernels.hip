@@ -842,8 +842,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
 // ------------------------------------------------------------------------------------------------------
 // THREADS: 256, or 1024 for scenes whose tables take a large part of a CU's LDS (one copy then serves sixteen
 // waves instead of four); work is claimed per wave, so nothing else depends on the block size.
-template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == kBlock ? 6 : 4))) void k_paths(
+// WAVES: waves per SIMD the register budget is set for.  Six fit without spilling and suit scenes served by LDS
+// or the caches; scenes read from HBM gain more from eight waves in flight than the few spilled registers cost.
+template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == kBlock ? WAVES : 4))) void k_paths(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
     uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
     extern __shared__ float4 s_scene[];
@@ -1073,7 +1075,12 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  uint32_t lds_bytes, bool big_blocks) {
+                  uint32_t lds_bytes, bool big_blocks, bool eight_waves) {
+    if (!lds_bytes && eight_waves) {
+        auto kernel = need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+        return;
+    }
     if (lds_bytes && big_blocks) {
         auto kernel = need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
         if (lds_bytes > 48u * 1024u)
