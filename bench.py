@@ -210,7 +210,7 @@ def main():
         # HBM roofline above cannot show): wave-level VALU instructions per ray, VALU-busy share of SIMD cycles
         # (4 cycles per wave64 instruction, 1024 SIMDs, GRBM_GUI_ACTIVE summed over the 8 XCDs) and lane utilisation.
         valu = None
-        pj = os.path.join(ROOT, "profiles", "r01_v6_pmc_summary_cornell1080p_paths_lds.txt")
+        pj = os.path.join(ROOT, "profiles", "r01_v8_pmc_summary_cornell1080p_paths_lds.txt")
         if os.path.exists(pj) and os.path.exists(tj):
             vals, on = {}, False
             for line in open(pj):
@@ -225,7 +225,7 @@ def main():
                 valu = {"wave_instructions_per_ray": vals["SQ_INSTS_VALU"] / pmc_rays,
                         "busy_share_of_simd_cycles": 4.0 * vals["SQ_ACTIVE_INST_VALU"] / simd_cycles,
                         "lane_utilisation": vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_INSTS_VALU"]),
-                        "source": "profiles/r01_v6_pmc_summary_cornell1080p_paths_lds.txt (PMC, not measured in this run; "
+                        "source": "profiles/r01_v8_pmc_summary_cornell1080p_paths_lds.txt (PMC, not measured in this run; "
                                   "the busy share divides counters of two profiling passes and reads slightly above 1 when "
                                   "the VALUs are saturated)"}
 
