@@ -6,7 +6,9 @@ all bounces) and — when more than one GPU takes part — adds the step's radia
 all-reduce.  Inputs (scene tables, camera) are resident in HBM before the timed region; the accumulators stay
 on the device.  One ray = one closest-hit query (`world.hit`, src/renderer.rs:44 of the reference).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 runs one rank per GPU: either a launcher (torch.distributed.run) has started the N ranks, or bench.py
+starts them itself as a child process.
 """
 from __future__ import annotations
 
@@ -69,7 +71,22 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a child process and before
+    # anything here touches the GPU, and pass its output and exit code on.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_device0 else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -81,6 +98,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
     n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -256,6 +275,7 @@ def main():
             "value": rays_all / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": n_gpus,
+            "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

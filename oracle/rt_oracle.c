@@ -662,8 +662,9 @@ static inline uint32_t rng_next_u32(rng_t *r) {
     if (r->mode == ORACLE_RNG_COUNTER) {
         /* 64-bit block b holds draws 2b (low half) and 2b+1 (high half). */
         uint32_t k = r->k++;
-        uint64_t c = r->path_key | (uint64_t)((k >> 1) & 0xFFFFu);
-        uint64_t bits = mix64(c * 0x9E3779B97F4A7C15ull + r->seed_mix);
+        uint32_t b = (k & 0x0FFFFFFFu) >> 1; /* the stream is defined for 2^28 draws per path */
+        uint64_t c = r->path_key | (uint64_t)(b & 0xFFFFu);
+        uint64_t bits = mix64(c * 0x9E3779B97F4A7C15ull + r->seed_mix + (uint64_t)(b >> 16) * 0xD6E8FEB86659FD93ull);
         return (k & 1u) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
     }
     uint64_t *s = r->s;

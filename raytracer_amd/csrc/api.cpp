@@ -267,7 +267,7 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
         c->owns_stream = true;
     }
     if (hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
-        delete c;
+        rt_context_destroy(c);
         return set_error(RT_ERR_DEVICE, "hipEventCreate failed");
     }
     *out = c;
@@ -500,6 +500,16 @@ RT_API int rt_camera_from_settings(const rt_camera_settings *s, uint32_t width, 
 // ------------------------------------------------------------------------------------------------------
 // closest hit
 // ------------------------------------------------------------------------------------------------------
+namespace {
+// LDS bytes the extend kernel of a closest-hit query stages the scene tables in (0: read them through the caches).
+uint32_t trace_lds_bytes(const rt_context *c, const rt_scene *s) {
+    const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
+    const bool want_lds = c->pipeline == RT_PIPELINE_AUTO || c->pipeline == RT_PIPELINE_FUSED_LDS ||
+                          c->pipeline == RT_PIPELINE_HYBRID_LDS || c->pipeline == RT_PIPELINE_SPLIT_LDS;
+    return want_lds && table_bytes <= 40u * 1024u ? (uint32_t)table_bytes : 0u;
+}
+} // namespace
+
 RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ray *d_rays, size_t n, float t_min,
                                    float t_max, int use_bvh, rt_hit *d_out, rt_stats *stats) {
     if (!c || !s) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest: null context or scene");
@@ -523,10 +533,7 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     if (int rc = timed_begin(c, K_EXTEND)) return rc;
     const rt::QueueView all{nullptr, nullptr, 0u, (uint32_t)n};
     const uint32_t grid = (uint32_t)std::min<uint64_t>(c->max_blocks, (n + 255) / 256);
-    const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
-    const bool want_lds = c->pipeline == RT_PIPELINE_AUTO || c->pipeline == RT_PIPELINE_FUSED_LDS ||
-                          c->pipeline == RT_PIPELINE_HYBRID_LDS || c->pipeline == RT_PIPELINE_SPLIT_LDS;
-    const uint32_t lds_bytes = want_lds && table_bytes <= 40u * 1024u ? (uint32_t)table_bytes : 0u;
+    const uint32_t lds_bytes = trace_lds_bytes(c, s);
     rt::launch_extend(c->stream, grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, all, t_min, t_max, use_bvh != 0,
                       count ? c->counters.ptr : nullptr, lds_bytes);
     if (int rc = timed_end(c)) return rc;
@@ -596,7 +603,9 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const size_t slots = (size_t)B * npix;
     if (slots > 0x7FFFFFFFull) return set_error(RT_ERR_INVALID_ARGUMENT, "batch exceeds 2^31 paths");
     const bool count = stats && (c->flags & RT_CTX_COUNTERS);
-    // Pipeline choice.  The instrumented extend kernel needs a pipeline that runs extend for every bounce.
+    // Pipeline choice.  The instrumented extend kernel needs a pipeline that runs extend for every bounce.  Scenes
+    // with Mix materials are rendered by the PATHS and SPLIT kernels only (the per-bounce fused kernel has no Mix
+    // instance): FUSED / HYBRID requests fall back to SPLIT for them.
     const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
     uint32_t pipeline = c->pipeline;
     // AUTO: tables up to 40 KB go to LDS once per 256-thread block; up to 150 KB once per 1024-thread block, one
@@ -604,11 +613,12 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_PATHS;
     bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
                pipeline == RT_PIPELINE_PATHS_LDS;
-    // Mix materials are evaluated by the split shade kernel only.
-    if (count || s->has_mix) {
+    if (count) {
         if (c->pipeline == RT_PIPELINE_AUTO && table_bytes > 64u * 1024u) lds = false;
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     }
+    if (s->has_mix && pipeline != RT_PIPELINE_PATHS && pipeline != RT_PIPELINE_PATHS_LDS)
+        pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     const bool big_blocks = pipeline == RT_PIPELINE_PATHS_LDS && table_bytes > 40u * 1024u;
     if (lds && table_bytes > (big_blocks ? 150u : 64u) * 1024u)
         return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
@@ -680,7 +690,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr, c->early.ptr,
-                             s->need_uv, lds_bytes, big_blocks, eight_waves);
+                             s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves);
             if (int rc = timed_end(c)) return rc;
             ++bounce_launches;
         }

@@ -21,7 +21,7 @@ void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float
 // Shades the items of `q`; block b appends its surviving slots at queue_out[b * q.cap ...], stores their
 // number in counts_out[b] and in early_out[b] the number of paths it ended because their next ray misses the
 // scene's root box (those rays count as traced in the next bounce).
-// `has_mix` selects the variant that evaluates Mix materials (only the split kernels carry that code).
+// `has_mix` selects the variant that evaluates Mix materials.
 void launch_shade(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
                   const QueueView &q, uint32_t *queue_out, uint32_t *counts_out, uint32_t *early_out, bool need_uv,
                   bool has_mix);
@@ -37,7 +37,7 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 // All bounces of a batch in one launch (k_paths); `counts` / `early` rows 1 .. max_depth must be zero.
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  uint32_t lds_bytes, bool big_blocks, bool eight_waves);
+                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves);
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals);
 

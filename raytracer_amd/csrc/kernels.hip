@@ -14,6 +14,9 @@ namespace rt {
 namespace {
 
 constexpr int kBlock = 256;
+// ray_o.w of an in-flight path: index of its next random draw in the low kDrawBits bits, NaN flags above.
+constexpr uint32_t kDrawBits = 28u;
+constexpr uint32_t kDrawMask = (1u << kDrawBits) - 1u;
 
 __device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
 __device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
@@ -187,12 +190,12 @@ struct Surface {
     uint32_t prim_id;
 };
 
-// src/object/sphere.rs:42-52.  Only evaluated for image-textured spheres; acosf/atan2f are the device
-// library's and may differ from the host libm by a few ULP.
+// Sphere::get_uv (src/object/sphere.rs:42-52); acos / atan2 are the restatements of glibc's acosf / atan2f in
+// rt_math.h, so the texture coordinates equal the host's bit for bit.
 __device__ __forceinline__ void sphere_uv(V3 p, float &u, float &v) {
     const float PI = 3.14159265358979323846f;
-    float theta = acosf(-p.y);
-    float phi = atan2f(-p.z, p.x) + PI;
+    float theta = acos_f32(-p.y);
+    float phi = atan2_f32(-p.z, p.x) + PI;
     u = phi / (2.0f * PI);
     v = theta / PI;
 }
@@ -459,7 +462,7 @@ __device__ __forceinline__ uint32_t generate_ray(const RenderParams &P, uint32_t
 }
 
 // Path state while a path is in flight (slot = sample_in_batch * npix + pixel):
-//   ray_o = origin.xyz    | k (bits 0..23: index of the next random draw) | NaN flags (bits 24..26)
+//   ray_o = origin.xyz    | k (bits 0..27: index of the next random draw) | NaN flags (bits 28..30)
 //   ray_d = direction.xyz | depth (bits 0..15) | sample_in_batch (bits 16..31)
 //   beta  = throughput.xyz
 // The radiance is not part of it: until a path ends its radiance is, per channel, either +0 or NaN (only
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams P, PathState s
         V3 origin, dir;
         uint32_t s_local, pixel;
         uint32_t k = generate_ray(P, slot, origin, dir, s_local, pixel);
-        st.ray_o[slot] = mk4(origin, u2f(k & 0xFFFFFFu));
+        st.ray_o[slot] = mk4(origin, u2f(k & kDrawMask));
         st.ray_d[slot] = mk4(dir, u2f(s_local << 16));
         st.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     }
@@ -704,7 +707,7 @@ __device__ __forceinline__ int shade_path(const SceneDev &sc, float4 root_lo, fl
             if (alive) {
                 // a scattering material emits nothing, so l is still +0 or NaN per channel here
                 flags = (l.x != l.x ? 1u : 0u) | (l.y != l.y ? 2u : 0u) | (l.z != l.z ? 4u : 0u);
-                st.ray_o[slot] = mk4(s.point, u2f((rng.k & 0xFFFFFFu) | (flags << 24)));
+                st.ray_o[slot] = mk4(s.point, u2f((rng.k & kDrawMask) | (flags << kDrawBits)));
                 st.ray_d[slot] = mk4(sr.direction, u2f((s_local << 16) | depth));
                 st.beta[slot] = mk4(beta, 0.0f);
             }
@@ -760,8 +763,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
             float4 b4 = st.beta[slot];
             Closest best{h.x, f2u(h.y), h.z, h.w};
             const uint32_t s_local = f2u(d4.w) >> 16;
-            alive = shade_path<NEED_UV, HAS_MIX>(sc, nodes[0], nodes[1], prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & 0xFFFFFFu,
-                                        f2u(o4.w) >> 24, f2u(d4.w) & 0xFFFFu, s_local, slot - s_local * P.npix, best);
+            alive = shade_path<NEED_UV, HAS_MIX>(sc, nodes[0], nodes[1], prims, P, st, slot, xyz(o4), xyz(d4), xyz(b4), f2u(o4.w) & kDrawMask,
+                                        f2u(o4.w) >> kDrawBits, f2u(d4.w) & 0xFFFFu, s_local, slot - s_local * P.npix, best);
         }
         compact_survivors(alive, slot, lane, &s_out, &s_early, queue_out, c.seg);
     }
@@ -814,8 +817,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
                 o = xyz(o4);
                 d = xyz(d4);
                 beta = xyz(st.beta[slot]);
-                k = f2u(o4.w) & 0xFFFFFFu;
-                flags = f2u(o4.w) >> 24;
+                k = f2u(o4.w) & kDrawMask;
+                flags = f2u(o4.w) >> kDrawBits;
                 depth = f2u(d4.w) & 0xFFFFu;
                 s_local = f2u(d4.w) >> 16;
                 pixel = slot - s_local * P.npix;
@@ -844,8 +847,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
 // waves instead of four); work is claimed per wave, so nothing else depends on the block size.
 // WAVES: waves per SIMD the register budget is set for.  Six fit without spilling and suit scenes served by LDS
 // or the caches; scenes read from HBM gain more from eight waves in flight than the few spilled registers cost.
-template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == kBlock ? WAVES : 4))) void k_paths(
+// HAS_MIX: the scene holds Mix materials (evaluated by scatter_material instead of scatter_leaf; its recursive
+// calls keep the instance at four waves per SIMD).
+template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREADS == kBlock && !HAS_MIX) ? WAVES : 4))) void k_paths(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
     uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
     extern __shared__ float4 s_scene[];
@@ -882,8 +887,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
             uint32_t s_local, pixel;
             const uint32_t k = generate_ray(P, slot, o, d, s_local, pixel);
             Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-            alive = shade_path<NEED_UV, false>(sc, root_lo, root_hi, prims, P, st, slot, o, d, V3{1.0f, 1.0f, 1.0f}, k, 0u, 0u,
-                                               s_local, pixel, best);
+            alive = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, V3{1.0f, 1.0f, 1.0f}, k, 0u, 0u,
+                                                 s_local, pixel, best);
         }
         compact_survivors(alive, slot, lane, &s_out, &s_early, queue0, seg);
     }
@@ -918,9 +923,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                 const V3 o = xyz(o4), d = xyz(d4);
                 const uint32_t s_local = f2u(d4.w) >> 16;
                 Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-                alive = shade_path<NEED_UV, false>(sc, root_lo, root_hi, prims, P, st, slot, o, d, xyz(st.beta[slot]),
-                                                   f2u(o4.w) & 0xFFFFFFu, f2u(o4.w) >> 24, f2u(d4.w) & 0xFFFFu, s_local,
-                                                   slot - s_local * P.npix, best);
+                alive = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, xyz(st.beta[slot]),
+                                                     f2u(o4.w) & kDrawMask, f2u(o4.w) >> kDrawBits, f2u(d4.w) & 0xFFFFu, s_local,
+                                                     slot - s_local * P.npix, best);
             }
             compact_survivors(alive, slot, lane, &s_out, &s_early, q_out, seg);
         }
@@ -1075,28 +1080,24 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  uint32_t lds_bytes, bool big_blocks, bool eight_waves) {
+                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves) {
+    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *);
+    Kernel kernel;
+    uint32_t threads = kBlock;
+    // Scenes with Mix materials use the instances that also interpolate texture coordinates.
     if (!lds_bytes && eight_waves) {
-        auto kernel = need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
-        return;
-    }
-    if (lds_bytes && big_blocks) {
-        auto kernel = need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
+        kernel = has_mix ? k_paths<false, true, kBlock, 8, true> : need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
+    } else if (lds_bytes && big_blocks) {
+        kernel = has_mix ? k_paths<true, true, 1024, 6, true> : need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
+        threads = 1024;
         if (lds_bytes > 48u * 1024u)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
     } else if (lds_bytes) {
-        if (need_uv)
-            hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(kBlock), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
-        else
-            hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(kBlock), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+        kernel = has_mix ? k_paths<true, true, kBlock, 6, true> : need_uv ? k_paths<true, true> : k_paths<true, false>;
     } else {
-        if (need_uv)
-            hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
-        else
-            hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+        kernel = has_mix ? k_paths<false, true, kBlock, 6, true> : need_uv ? k_paths<false, true> : k_paths<false, false>;
     }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
 }
 
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,

@@ -129,11 +129,149 @@ RT_HD float cos_unit(float y) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// acos / atan2 for Sphere::get_uv (src/object/sphere.rs:42-52).  The reference calls the platform libm through
+// f32::acos / f32::atan2; on Linux that is glibc's acosf / atan2f, which up to glibc 2.40 are the binary32
+// fdlibm routines (rational approximation of asin on three ranges; atan by argument reduction to one of four
+// break points and an 11-term polynomial).  This is a restatement of that published algorithm and its
+// coefficient tables in binary32 arithmetic, one IEEE operation per source operation; a host-side comparison
+// with glibc 2.35 (every binary32 for acosf and atanf, 10^9 argument pairs for atan2f) matches bit for bit.
+// ------------------------------------------------------------------------------------------------------
+namespace invtrig_detail {
+RT_HD float asin_ratio(float z) {
+    const float pS0 = u2f(0x3e2aaaabu), pS1 = u2f(0xbea6b090u), pS2 = u2f(0x3e4e0aa8u), pS3 = u2f(0xbd241146u),
+                pS4 = u2f(0x3a4f7f04u), pS5 = u2f(0x3811ef08u);
+    const float qS1 = u2f(0xc019d139u), qS2 = u2f(0x4001572du), qS3 = u2f(0xbf303361u), qS4 = u2f(0x3d9dc62eu);
+    float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    return p / q;
+}
+} // namespace invtrig_detail
+
+RT_HD float acos_f32(float x) {
+    using namespace invtrig_detail;
+    const float pi = u2f(0x40490fdau), pio2_hi = u2f(0x3fc90fdau), pio2_lo = u2f(0x33a22168u);
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) { // |x| < 0.5
+        if (ix <= 0x32800000) return pio2_hi + pio2_lo;
+        float r = asin_ratio(x * x);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) { // x < -0.5
+        float z = (1.0f + x) * 0.5f;
+        float r = asin_ratio(z);
+        float s = sqrtf(z);
+        float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    float z = (1.0f - x) * 0.5f; // x > 0.5
+    float s = sqrtf(z);
+    float df = u2f(f2u(s) & 0xfffff000u);
+    float c = (z - df * df) / (s + df);
+    float r = asin_ratio(z);
+    float w = r * s + c;
+    return 2.0f * (df + w);
+}
+
+RT_HD float atan_f32(float x) {
+    const float atanhi[4] = {u2f(0x3eed6338u), u2f(0x3f490fdau), u2f(0x3f7b985eu), u2f(0x3fc90fdau)};
+    const float atanlo[4] = {u2f(0x31ac3769u), u2f(0x33222168u), u2f(0x33140fb4u), u2f(0x33a22168u)};
+    const float aT[11] = {u2f(0x3eaaaaabu), u2f(0xbe4ccccdu), u2f(0x3e124925u), u2f(0xbde38e38u), u2f(0x3dba2e6eu),
+                          u2f(0xbd9d8795u), u2f(0x3d886b35u), u2f(0xbd6ef16bu), u2f(0x3d4bda59u), u2f(0xbd15a221u),
+                          u2f(0x3c8569d7u)};
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) { // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) { // |x| < 0.4375
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) {
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else if (ix < 0x401c0000) {
+            id = 2;
+            x = (x - 1.5f) / (1.0f + 1.5f * x);
+        } else {
+            id = 3;
+            x = -1.0f / x;
+        }
+    }
+    float z = x * x;
+    float w = z * z;
+    float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return hx < 0 ? -z : z;
+}
+
+RT_HD float atan2_f32(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = u2f(0x3f490fdbu), pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu),
+                pi_lo = u2f(0xb3bbbd2eu);
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return atan_f32(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) {
+        if (m < 2) return y;
+        return m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0f * pi_o_4 + tiny;
+            default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+        case 0: return 0.0f;
+        case 1: return -0.0f;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = atan_f32(fabsf(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return u2f(f2u(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Per-path random stream.  The reference draws from a thread-local SmallRng seeded from OS entropy
 // (src/random.rs:8-14), which cannot be reproduced; here draw k of path (pixel, sample) is a pure function
 // of (seed, pixel, sample, k): 64-bit block b = mix64((sample<<42 | pixel<<16 | b) * golden + mix64(seed))
 // holds draws 2b (low half) and 2b+1 (high half).  mix64 is the splitmix64 finaliser, a bijection, so
-// distinct (pixel, sample, b) never share a block.
+// distinct (pixel, sample, b) with b < 65536 never share a block; later blocks (see rng_block) are distinct hash
+// inputs with overwhelming probability only.  The kernels carry k in 28 bits: a path's stream is defined for its
+// first 2^28 draws (max_depth is at most 65535, so that is 4096 draws per bounce).
 // ------------------------------------------------------------------------------------------------------
 RT_HD uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -157,7 +295,9 @@ RT_HD Rng rng_for_path(uint64_t seed_mix, uint32_t pixel, uint32_t sample, uint3
 
 RT_HD uint64_t rng_block(const Rng &r, uint32_t b) {
     uint64_t c = r.path_key | (uint64_t)(b & 0xFFFFu);
-    return mix64(c * 0x9E3779B97F4A7C15ull + r.seed_mix);
+    // Blocks beyond the 16 bits the key has room for (a path's draws from number 131072 on) are told apart by a
+    // second odd multiple added to the hash input; the first 65536 blocks have b >> 16 == 0.
+    return mix64(c * 0x9E3779B97F4A7C15ull + r.seed_mix + (uint64_t)(b >> 16) * 0xD6E8FEB86659FD93ull);
 }
 
 RT_HD uint32_t rng_next_u32(Rng &r) {

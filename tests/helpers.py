@@ -233,3 +233,52 @@ def random_scene(seed):
     cs = CameraSettings.look_at(tuple(eye), (0.0, 0.0, 0.0), 40.0 + 30.0 * rng.random(), focus_dist=float(np.linalg.norm(eye)),
                                 defocus_angle=float(rng.choice([0.0, 0.0, 2.0])), z_near=1e-3)
     return sc, cs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Converged-image tolerance: an image `g` rendered with one random stream against two renders `a`, `b` of the
+# same scene with the reference's generator (per-thread xoshiro256++) under two different seeds.  All three are
+# means over the same number of samples, shape (H, W, 3).
+#   sigma_mc   per channel, the Monte-Carlo standard deviation of a pixel's mean: RMSE(a, b) / sqrt(2) over the
+#              pixels finite in all three images
+#   rmse       per channel RMSE(g, a) and RMSE(g, b) over the same pixels must be <= 3 sigma_mc (two independent
+#              unbiased renders differ by sqrt(2) sigma_mc), and their ratio to RMSE(a, b) must lie in
+#              [0.75, 1.33] (same per-pixel variance)
+#   luminance  mean Rec. 709 luminance over each image's finite pixels: |lum(g) - lum(a or b)| <= the larger of
+#              1 % and four standard errors of that difference (from the per-pixel variance)
+#   inf        fraction of pixels holding an infinity: within 20 % (relative) of a's and b's, plus 2e-4 absolute
+# ---------------------------------------------------------------------------------------------------------
+def image_tolerance_report(g, a, b):
+    g, a, b = (np.asarray(x, dtype=np.float64) for x in (g, a, b))
+    fin = (np.isfinite(g) & np.isfinite(a) & np.isfinite(b)).all(axis=2)
+    rep = {"finite_pixels": int(fin.sum()), "channels": []}
+    for c in range(3):
+        rm = lambda x, y: float(np.sqrt(np.mean((x[..., c][fin] - y[..., c][fin]) ** 2)))
+        ab, ga, gb = rm(a, b), rm(g, a), rm(g, b)
+        rep["channels"].append({"sigma_mc": ab / np.sqrt(2.0), "rmse_ab": ab, "rmse_ga": ga, "rmse_gb": gb})
+    w = np.array([0.2126, 0.7152, 0.0722])
+    lum = lambda x: (x @ w)
+    la, lb, lg = lum(a), lum(b), lum(g)
+    mean_fin = lambda l: float(l[np.isfinite(l)].mean())
+    rep["lum"] = {"g": mean_fin(lg), "a": mean_fin(la), "b": mean_fin(lb),
+                  # standard error of one image's mean luminance, from the per-pixel variance (a - b)^2 / 2
+                  "stderr": float(np.sqrt(np.sum((la[fin] - lb[fin]) ** 2 / 2.0)) / max(1, fin.sum()))}
+    rep["inf"] = {k: float(np.isinf(x).any(axis=2).mean()) for k, x in (("g", g), ("a", a), ("b", b))}
+    return rep
+
+
+def assert_image_within_tolerance(g, a, b):
+    rep = image_tolerance_report(g, a, b)
+    assert rep["finite_pixels"] > 0.5 * g.shape[0] * g.shape[1], rep
+    for ch in rep["channels"]:
+        for k in ("rmse_ga", "rmse_gb"):
+            assert ch[k] <= 3.0 * ch["sigma_mc"] + 1e-12, rep
+            assert 0.75 * ch["rmse_ab"] - 1e-12 <= ch[k] <= 1.33 * ch["rmse_ab"] + 1e-12, rep
+    lum = rep["lum"]
+    for k in ("a", "b"):
+        tol = max(0.01 * abs(lum[k]), 4.0 * np.sqrt(2.0) * lum["stderr"])
+        assert abs(lum["g"] - lum[k]) <= tol, rep
+    inf = rep["inf"]
+    for k in ("a", "b"):
+        assert abs(inf["g"] - inf[k]) <= 0.2 * max(inf["g"], inf[k]) + 2e-4, rep
+    return rep

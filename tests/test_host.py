@@ -130,6 +130,39 @@ def test_device_sincos_matches_libm_on_host():
     assert checked > 3.4e7 and bad_s == 0 and bad_c == 0
 
 
+def test_device_acos_atan2_match_libm_on_host():
+    """rt::acos_f32 / rt::atan_f32 / rt::atan2_f32 (Sphere::get_uv on the GPU), compiled for the host from the
+    same header the kernels include, equal glibc's acosf / atanf / atan2f bit for bit (every 127th binary32 and
+    two million argument pairs plus the special values here; the exhaustive sweep of all 2^32 arguments and 10^9
+    pairs also reports zero mismatches against glibc 2.35)."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "invtrig_check")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+                               os.path.join(ROOT, "tests", "native", "invtrig_check.cpp"), "-o", exe, "-lm"])
+        out = subprocess.run([exe, "127", "1000000"], capture_output=True, text=True, check=True).stdout.split()
+    n1, b1, n2, b2, n3, b3 = (int(x) for x in out)
+    assert n1 > 3.3e7 and n3 > 2e6 and (b1, b2, b3) == (0, 0, 0)
+
+
+def test_random_stream_of_the_kernels_equals_the_oracles_beyond_131072_draws():
+    """The per-path random stream of the kernels (rt_math.h, compiled for the host here; the kernels include the
+    same header) against the oracle's separate implementation: the first 400000 draws of a few paths, which
+    crosses draw 131072 where the block index outgrows the 16 bits the hash key has room for, and the float
+    conversions of both."""
+    from oracle import binding as ob
+
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "rng_dump")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "rng_dump.cpp"), "-o", exe])
+        for seed, pixel, sample in ((1, 0, 0), (7, 2073599, 1023), (0xDEADBEEF12345678, (1 << 26) - 1, (1 << 22) - 1)):
+            raw = subprocess.run([exe, str(seed), str(pixel), str(sample), "400000"], capture_output=True, check=True).stdout
+            mine = np.frombuffer(raw, dtype=np.uint32)
+            want = ob.rng_draws(seed, pixel, sample, 400000)
+            assert len(mine) == 400000 and np.array_equal(mine, want)
+            assert len(np.unique(mine[131072:262144])) > 131000  # the later blocks are not a replay of the first
+            assert not np.array_equal(mine[:131072], mine[131072:262144])
+
+
 def test_product_fails_loudly_without_a_gpu():
     """No CPU fallback: without a HIP device a context cannot be created and the error says so."""
     import torch

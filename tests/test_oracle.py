@@ -111,11 +111,34 @@ def check_bvh_structure(boxes, prim, skip, n_prims):
     assert np.all(boxes[:, 3:] - boxes[:, :3] >= 0.00099), "pad_to_minimums (src/aabb.rs:78-93)"
 
 
+def check_bvh_structure_vectorised(boxes, prim, skip, n_prims):
+    """check_bvh_structure for trees too large for a Python loop (same assertions, numpy over all nodes)."""
+    n = len(prim)
+    assert n == 2 * n_prims - 1 and skip[0] == n
+    leaf = prim >= 0
+    assert np.array_equal(np.sort(prim[leaf]), np.arange(n_prims)), "every primitive in exactly one leaf"
+    idx = np.arange(n, dtype=np.int64)
+    sk = skip.astype(np.int64)
+    assert np.array_equal(sk[leaf], idx[leaf] + 1)
+    i = idx[~leaf]
+    left = i + 1
+    right = sk[left]
+    assert np.all((left < right) & (right < sk[i]) & (sk[i] <= n))
+    assert np.array_equal(sk[right], sk[i])
+    for c in (left, right):
+        assert np.all(boxes[c, :3] >= boxes[i, :3]) and np.all(boxes[c, 3:] <= boxes[i, 3:])
+    sub = sk[i] - i
+    assert np.all(sub % 2 == 1)
+    assert np.array_equal((right - left + 1) // 2, ((sub + 1) // 2) // 2), "mid = len / 2 (src/bvh.rs:268)"
+    assert np.all(boxes[:, 3:] - boxes[:, :3] >= 0.00099), "pad_to_minimums (src/aabb.rs:78-93)"
+
+
 def test_bvh_structure(cornell, teapot):
     for desc in (cornell, teapot):
         o = ob.OracleScene(desc)
         boxes, prim, skip = o.export_bvh()
         check_bvh_structure(boxes, prim, skip, desc.num_primitives)
+        check_bvh_structure_vectorised(boxes, prim, skip, desc.num_primitives)
     i = ob.OracleScene(cornell).info()
     assert (i.num_triangles, i.num_nodes, i.depth) == (36, 71, 7)
     # root box = padded union of the scene (src/main.rs:92-95)
@@ -227,16 +250,24 @@ def test_sample_ranges_add_up(cornell):
 
 
 def test_thread_rng_mode_is_statistically_consistent(cornell):
-    """The xoshiro256++ per-thread stream (the reference's SmallRng algorithm) and the counter stream give
-    the same image up to Monte-Carlo noise."""
+    """The counter stream against the xoshiro256++ per-thread stream (the reference's SmallRng algorithm,
+    src/random.rs:8-14) at equal spp: per-channel RMSE, mean luminance and inf-pixel fraction within the stated
+    tolerance (helpers.assert_image_within_tolerance), the thread-stream noise level taken from two seeds.  The
+    GPU renders with the counter stream bit for bit like the oracle in this mode, so this is the CPU half of the
+    converged-image comparison; the GPU half is test_gpu_parity.test_converged_images_match_the_reference_rng."""
+    from helpers import assert_image_within_tolerance
+
     o = ob.OracleScene(cornell)
-    cam = ob.camera_from_settings(cornell.camera(0), 64, 64)
-    rs = RenderSettings(64, 64, 0, 50, 32, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=5)
-    a, _ = o.render(cam, rs, threads=8, rng_mode=ob.RNG_COUNTER)
-    b, _ = o.render(cam, rs, threads=8, rng_mode=ob.RNG_THREAD)
-    fin = np.isfinite(a) & np.isfinite(b)
-    ma, mb = a[fin].mean() / 32, b[fin].mean() / 32
-    assert abs(ma - mb) < 0.03 * max(ma, mb)
+    w = h = 96
+    spp = 96
+    cam = ob.camera_from_settings(cornell.camera(0), w, h)
+    imgs = []
+    for mode, seed in ((ob.RNG_COUNTER, 5), (ob.RNG_THREAD, 6), (ob.RNG_THREAD, 7)):
+        rs = RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=seed)
+        img, _ = o.render(cam, rs, threads=8, rng_mode=mode)
+        imgs.append(img / np.float32(spp))
+    rep = assert_image_within_tolerance(*imgs)
+    assert rep["inf"]["g"] > 0.01  # the reference's degenerate samples do poison pixels (SmallRng or not)
 
 
 def test_rng_stream_properties():
