@@ -192,6 +192,8 @@ pub enum rt_context {}
 pub enum rt_scene {}
 pub enum rt_gltf {}
 
+pub const RT_NOALLOC_MAX_RAYS: usize = 65536;
+
 extern "C" {
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_device_count() -> c_int;
@@ -211,6 +213,9 @@ extern "C" {
                             t_max: f32, use_bvh: c_int, out: *mut rt_hit, stats: *mut rt_stats) -> c_int;
     pub fn rt_trace_closest_device(ctx: *mut rt_context, scene: *const rt_scene, d_rays: *const rt_ray, n: usize,
                                    t_min: f32, t_max: f32, use_bvh: c_int, d_out: *mut rt_hit, stats: *mut rt_stats) -> c_int;
+    /// Allocation-free variant of `rt_trace_closest_device` (at most `RT_NOALLOC_MAX_RAYS` rays per call).
+    pub fn rt_trace_closest_noalloc(ctx: *mut rt_context, scene: *const rt_scene, d_rays: *const rt_ray, n: usize,
+                                    t_min: f32, t_max: f32, use_bvh: c_int, d_out: *mut rt_hit) -> c_int;
     pub fn rt_render(ctx: *mut rt_context, scene: *const rt_scene, camera: *const rt_camera, settings: *const rt_settings,
                      accum: *mut f32, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_device(ctx: *mut rt_context, scene: *const rt_scene, camera: *const rt_camera,

@@ -329,6 +329,19 @@ int rt_trace_closest(rt_context *ctx, const rt_scene *scene, const rt_ray *rays,
 int rt_trace_closest_device(rt_context *ctx, const rt_scene *scene, const rt_ray *d_rays, size_t n,
                             float t_min, float t_max, int use_bvh, rt_hit *d_out, rt_stats *stats);
 
+/* rt_trace_closest_device without any allocation.  No counterpart in the reference: it exists for callers that
+ * cannot allocate device memory while they run — code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same kernels and same results as rt_trace_closest_device (no statistics); the ray and hit
+ * staging that call keeps in the context's workspace lives here in a fixed array in device memory that the library
+ * holds on every GPU it runs on until the process ends (RT_NOALLOC_MAX_RAYS x 48 bytes = 3 MiB), whose address
+ * was resolved when the context was created.  The call allocates and frees nothing, on the host or the device;
+ * `n` > RT_NOALLOC_MAX_RAYS is refused with RT_ERR_INVALID_ARGUMENT.  Asynchronous on the context's stream.  All
+ * calls on one GPU share that GPU's array: calls on different streams or from different contexts of the same
+ * device that overlap in time race on it; calls on one stream are ordered and safe. */
+#define RT_NOALLOC_MAX_RAYS 65536u
+int rt_trace_closest_noalloc(rt_context *ctx, const rt_scene *scene, const rt_ray *d_rays, size_t n, float t_min,
+                             float t_max, int use_bvh, rt_hit *d_out);
+
 /* `Renderer::render` / passes of `Renderer::render_progressive` (src/renderer.rs:72-156) for the samples
  * [sample_begin, sample_begin + sample_count) of every pixel.  Writes UN-NORMALISED sums over those samples
  * into `accum` (host memory, 3 * width * height floats, row-major RGB, index 3 * (j * width + i) + c as in

@@ -25,6 +25,7 @@ RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE = 0, 1, 2
  RT_MAT_TROWBRIDGE_REITZ) = range(6)
 RT_MODE_LINEAR_MEAN, RT_MODE_GAMMA_PER_SAMPLE = 0, 1
 RT_MISS = 0xFFFFFFFF
+RT_NOALLOC_MAX_RAYS = 65536
 RT_CTX_TIMING, RT_CTX_COUNTERS = 1, 2
 (RT_PIPELINE_AUTO, RT_PIPELINE_SPLIT, RT_PIPELINE_FUSED, RT_PIPELINE_FUSED_LDS, RT_PIPELINE_HYBRID,
  RT_PIPELINE_HYBRID_LDS, RT_PIPELINE_SPLIT_LDS, RT_PIPELINE_PATHS, RT_PIPELINE_PATHS_LDS) = range(9)
@@ -135,6 +136,7 @@ EXPORTS = {
                                    C.POINTER(rt_stats)]),
     "rt_trace_closest_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_float, C.c_float, C.c_int, _vp,
                                           C.POINTER(rt_stats)]),
+    "rt_trace_closest_noalloc": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_float, C.c_float, C.c_int, _vp]),
     "rt_render": (C.c_int, [_vp, _vp, C.POINTER(rt_camera), C.POINTER(rt_settings), _vp,
                             C.POINTER(rt_stats)]),
     "rt_gltf_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),

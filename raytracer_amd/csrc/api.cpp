@@ -94,6 +94,7 @@ struct rt_context {
     uint64_t max_paths = 1ull << 26;
     uint32_t timed_bounces = 0xFFFFFFFFu;
     uint32_t pipeline = RT_PIPELINE_AUTO;
+    float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
     // wavefront workspace
     DevBuf<float4> ray_o, ray_d, hit, beta, radiance;
@@ -269,6 +270,13 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
     if (hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
         rt_context_destroy(c);
         return set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+    }
+    // Resolved here, with the context's device current, so that rt_trace_closest_noalloc itself has no set-up to do.
+    const char *why = nullptr;
+    c->noalloc_scratch = rt::noalloc_scratch_of_current_device(&why);
+    if (!c->noalloc_scratch) {
+        rt_context_destroy(c);
+        return set_error(RT_ERR_DEVICE, "hipGetSymbolAddress(scratch) on device %d: %s", device, why ? why : "no address");
     }
     *out = c;
     return RT_OK;
@@ -556,6 +564,30 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
         }
         if (int rc = collect_timing(c, stats)) return rc;
     }
+    return RT_OK;
+}
+
+// The allocation-free variant of rt_trace_closest_device: same kernels, with the ray and hit staging in the
+// device's file-scope scratch array instead of the context's workspace.  Nothing here allocates or frees.
+RT_API int rt_trace_closest_noalloc(rt_context *c, const rt_scene *s, const rt_ray *d_rays, size_t n, float t_min,
+                                    float t_max, int use_bvh, rt_hit *d_out) {
+    if (!c || !s) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest_noalloc: null context or scene");
+    if (s->device != c->device) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and context are on different devices");
+    if (n > rt::kNoAllocMaxRays)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest_noalloc: %zu rays exceed the limit of %u per call", n,
+                         rt::kNoAllocMaxRays);
+    if (n == 0) return RT_OK;
+    if (!d_rays || !d_out) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest_noalloc: null ray or hit buffer");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return set_error(RT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+    float4 *ray_o = c->noalloc_scratch, *ray_d = ray_o + rt::kNoAllocMaxRays, *hits = ray_d + rt::kNoAllocMaxRays;
+    rt::launch_pack_rays(c->stream, c->max_blocks, reinterpret_cast<const float *>(d_rays), (uint32_t)n, ray_o, ray_d);
+    const rt::QueueView all{nullptr, nullptr, 0u, (uint32_t)n};
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(c->max_blocks, (n + 255) / 256);
+    rt::launch_extend(c->stream, grid, s->dev, ray_o, ray_d, hits, all, t_min, t_max, use_bvh != 0, nullptr,
+                      trace_lds_bytes(c, s));
+    rt::launch_finalize_hits(c->stream, c->max_blocks, s->dev, ray_o, ray_d, hits, (uint32_t)n, d_out);
+    HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 

@@ -48,4 +48,11 @@ void launch_pack_rays(hipStream_t s, uint32_t max_blocks, const float *rays, uin
 void launch_finalize_hits(hipStream_t s, uint32_t max_blocks, const SceneDev &sc, const float4 *ray_o,
                           const float4 *ray_d, const float4 *hits, uint32_t n, void *out);
 
+// Device scratch of the allocation-free entry point (rt_trace_closest_noalloc): a file-scope array in device memory,
+// kNoAllocMaxRays slots of ray origin, ray direction and hit record (48 bytes each).  Every GPU holds its own copy
+// at its own address; this returns the address of the CURRENT device's copy (resolved once per device) or nullptr
+// with `error` set to the HIP error string.
+constexpr uint32_t kNoAllocMaxRays = 1u << 16;
+float4 *noalloc_scratch_of_current_device(const char **error);
+
 } // namespace rt

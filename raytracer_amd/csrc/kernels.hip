@@ -6,6 +6,8 @@
 // operation order (built with -ffp-contract=off), including its inf/NaN behaviour.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "kernels.h"
 #include "rt_math.h"
 
@@ -847,8 +849,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
 // waves instead of four); work is claimed per wave, so nothing else depends on the block size.
 // WAVES: waves per SIMD the register budget is set for.  Six fit without spilling and suit scenes served by LDS
 // or the caches; scenes read from HBM gain more from eight waves in flight than the few spilled registers cost.
-// HAS_MIX: the scene holds Mix materials (evaluated by scatter_material instead of scatter_leaf; its recursive
-// calls keep the instance at four waves per SIMD).
+// HAS_MIX: the scene holds Mix materials (evaluated by scatter_material instead of scatter_leaf).
 template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREADS == kBlock && !HAS_MIX) ? WAVES : 4))) void k_paths(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
@@ -1098,6 +1099,37 @@ void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
         kernel = has_mix ? k_paths<false, true, kBlock, 6, true> : need_uv ? k_paths<false, true> : k_paths<false, false>;
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Scratch of the allocation-free closest-hit entry point.  The array's name is only a host-side handle: host code
+// must go through the address hipGetSymbolAddress returns for the device that is current, and each device has
+// its own.  The contents are whatever the last call on that device left; every call writes the slots it reads.
+// ------------------------------------------------------------------------------------------------------
+static __device__ __align__(256) float4 scratch[3 * kNoAllocMaxRays];
+
+float4 *noalloc_scratch_of_current_device(const char **error) {
+    constexpr int kMaxDevices = 64;
+    static float4 *ptr_of_device[kMaxDevices] = {};
+    static std::mutex mutex;
+    int device = -1;
+    hipError_t e = hipGetDevice(&device);
+    if (e == hipSuccess && (device < 0 || device >= kMaxDevices)) e = hipErrorInvalidDevice;
+    if (e != hipSuccess) {
+        if (error) *error = hipGetErrorString(e);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(mutex);
+    if (!ptr_of_device[device]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            if (error) *error = hipGetErrorString(e);
+            return nullptr;
+        }
+        ptr_of_device[device] = static_cast<float4 *>(p);
+    }
+    return ptr_of_device[device];
 }
 
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
