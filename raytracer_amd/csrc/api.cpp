@@ -94,6 +94,7 @@ struct rt_context {
     uint64_t max_paths = 1ull << 26;
     uint32_t timed_bounces = 0xFFFFFFFFu;
     uint32_t pipeline = RT_PIPELINE_AUTO;
+    int traversal = 0;                // -1 walk, +1 stack, 0 = chosen per scene (environment variable RT_TRAVERSAL)
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
     // wavefront workspace
@@ -103,6 +104,7 @@ struct rt_context {
     DevBuf<uint32_t> early;               // [max_depth + 1][grid] early misses per block and bounce
     DevBuf<unsigned long long> totals;    // [max_depth + 1] per-bounce sums of `counts`
     DevBuf<rt::ExtendCounters> counters;
+    DevBuf<uint2> stack_spill;            // [tree depth][grid threads] traversal-stack entries beyond the LDS part
     DevBuf<float> accum;     // rt_render's device image
     DevBuf<float> ray_stage; // rt_trace_closest's device copies
     DevBuf<uint32_t> hit_stage;
@@ -123,7 +125,7 @@ struct rt_context {
 struct rt_scene {
     int device = 0;
     rt::SceneDev dev{};
-    void *blocks[8] = {};
+    void *blocks[10] = {};
     int n_blocks = 0;
     std::vector<uint32_t> prim_of_slot;
     rt_scene_info info{};
@@ -216,7 +218,7 @@ template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **ds
     *dst = nullptr;
     size_t n = v.size() ? v.size() : 1;
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+    HIP_TRY(hipMalloc(&p, n * sizeof(T) + 64)); // slack: the stack traversal reads 64 bytes at a 48-byte record
     s->blocks[s->n_blocks++] = p;
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T *>(p);
@@ -255,6 +257,8 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
         long v = std::strtol(e, nullptr, 10);
         if (v >= 1 && v <= 64) c->blocks_per_cu = (uint32_t)v;
     }
+    if (const char *e = std::getenv("RT_TRAVERSAL")) // tuning knob for experiments: "walk" or "stack"
+        c->traversal = !std::strcmp(e, "walk") ? -1 : !std::strcmp(e, "stack") ? 1 : 0;
     c->cus = (uint32_t)std::max(1, prop.multiProcessorCount);
     c->max_blocks = c->cus * 8u;
     if (stream) {
@@ -297,6 +301,7 @@ RT_API int rt_context_destroy(rt_context *c) {
     c->early.release();
     c->totals.release();
     c->counters.release();
+    c->stack_spill.release();
     c->accum.release();
     c->ray_stage.release();
     c->hit_stage.release();
@@ -402,6 +407,26 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
     }
     s->dev.n_nodes = d_nodes ? (uint32_t)n_nodes_device : (uint32_t)hs.nodes.size();
     s->dev.n_prims = (uint32_t)hs.prims.size();
+    // The 64-byte records of the stack traversal, derived on the device from the node table just uploaded.
+    s->dev.depth = hs.depth;
+    s->dev.root_ref = root.leaf == rt::kInterior ? 0u
+                                                 : (rt::kRefLeaf | ((root.leaf & rt::kSphereBit) ? rt::kRefSphere : 0u) | (root.leaf & ~rt::kSphereBit));
+    if (s->dev.n_prims <= rt::kRefIndex) {
+        void *p = nullptr;
+        const size_t wide_bytes = (size_t)std::max<uint32_t>(1u, s->dev.n_prims - 1u) * sizeof(rt::WideNode);
+        if (hipMalloc(&p, wide_bytes) != hipSuccess) {
+            rt_scene_destroy(s);
+            return set_error(RT_ERR_OUT_OF_MEMORY, "out of device memory for the BVH node records");
+        }
+        s->blocks[s->n_blocks++] = p;
+        s->dev.wide = static_cast<const rt::WideNode *>(p);
+        rt::build_wide_nodes(c->stream, s->dev.nodes, s->dev.n_nodes, static_cast<rt::WideNode *>(p));
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+            rt_scene_destroy(s);
+            return set_error(RT_ERR_DEVICE, "building the BVH node records failed");
+        }
+        bytes += wide_bytes;
+    }
     s->dev.n_materials = (uint32_t)hs.materials.size();
     s->dev.n_textures = (uint32_t)hs.textures.size();
     s->need_uv = hs.need_uv;
@@ -658,7 +683,13 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const bool paths = pipeline == RT_PIPELINE_PATHS || pipeline == RT_PIPELINE_PATHS_LDS;
     const bool fused_all = paths || pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
     const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
-    const uint32_t lds_bytes = lds ? (uint32_t)table_bytes : 0u;
+    // Traversal of the PATHS kernels: the stack traversal over 64-byte records, or the stackless walk over the
+    // 32-byte node table.
+    const uint64_t wide_table_bytes = (uint64_t)(s->dev.n_prims - 1u) * sizeof(rt::WideNode) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim) + 16u;
+    const uint64_t stack_lds_bytes = (uint64_t)rt::kStackEntriesInLds * (big_blocks ? 1024u : 256u) * sizeof(uint2);
+    const bool stack = paths && s->dev.wide && (c->traversal > 0 || (c->traversal == 0 && !lds)) &&
+                       (!lds || wide_table_bytes + stack_lds_bytes <= 159u * 1024u);
+    const uint32_t lds_bytes = lds ? (uint32_t)(stack ? wide_table_bytes : table_bytes) : 0u;
     // One grid for every bounce of a batch: block b owns segment b of both queues (see QueueView).
     const uint32_t chunks = (uint32_t)((slots + 255) / 256);
     // A CU holds six of these 256-thread blocks (six waves per SIMD) and whole rounds of six run best.  Scenes
@@ -675,6 +706,12 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const uint32_t grid = std::min(c->cus * blocks_per_cu, chunks);
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
     if (int rc = ensure_render(c, slots, (size_t)grid * cap, st->max_depth, grid)) return rc;
+    const uint32_t block_threads = big_blocks ? 1024u : 256u;
+    rt::StackSpill spill{nullptr, grid * block_threads};
+    if (stack) {
+        if (int rc = c->stack_spill.ensure((size_t)std::max(1u, s->dev.depth) * spill.stride)) return rc;
+        spill.spill = c->stack_spill.ptr;
+    }
     const uint32_t n_batches = (total + B - 1) / B;
     const size_t counts_len = (size_t)st->max_depth + 1;
     if (stats)
@@ -722,7 +759,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr, c->early.ptr,
-                             s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves);
+                             s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves, stack, spill);
             if (int rc = timed_end(c)) return rc;
             ++bounce_launches;
         }

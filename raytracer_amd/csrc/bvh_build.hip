@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <string>
 
 #include "bvh_build.h"
@@ -241,6 +242,44 @@ struct Scratch {
     } while (0)
 
 } // namespace
+
+namespace {
+
+// Leaf slots are numbered in pre-order, so the leaves that precede node i in pre-order number slot(leftmost leaf
+// under i), and the interior nodes that precede it i minus that: the record index of an interior node.
+__device__ __forceinline__ uint32_t leaves_before(const Node *__restrict__ nodes, uint32_t i) {
+    uint32_t leaf = nodes[i].leaf;
+    while (leaf == kInterior) leaf = nodes[++i].leaf;
+    return leaf & ~kSphereBit;
+}
+
+__device__ __forceinline__ uint32_t child_ref(const Node *__restrict__ nodes, uint32_t c) {
+    const uint32_t leaf = nodes[c].leaf;
+    if (leaf == kInterior) return c - leaves_before(nodes, c);
+    return kRefLeaf | ((leaf & kSphereBit) ? kRefSphere : 0u) | (leaf & ~kSphereBit);
+}
+
+__global__ __launch_bounds__(kThreads) void k_wide(const Node *__restrict__ nodes, uint32_t n_nodes, WideNode *__restrict__ wide) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_nodes; i += gridDim.x * kThreads) {
+        if (nodes[i].leaf != kInterior) continue;
+        const uint32_t l = i + 1, r = nodes[l].skip;
+        const Node a = nodes[l], b = nodes[r];
+        WideNode w;
+        w.lx[0] = a.xlo, w.lx[1] = a.xhi, w.ly[0] = a.ylo, w.ly[1] = a.yhi, w.lz[0] = a.zlo, w.lz[1] = a.zhi;
+        w.rx[0] = b.xlo, w.rx[1] = b.xhi, w.ry[0] = b.ylo, w.ry[1] = b.yhi, w.rz[0] = b.zlo, w.rz[1] = b.zhi;
+        w.left = child_ref(nodes, l);
+        w.right = child_ref(nodes, r);
+        w.pad[0] = w.pad[1] = 0u;
+        wide[i - leaves_before(nodes, i)] = w;
+    }
+}
+
+} // namespace
+
+void build_wide_nodes(hipStream_t stream, const Node *d_nodes, uint32_t n_nodes, WideNode *d_wide) {
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_nodes + kThreads - 1) / kThreads, 1u << 16);
+    hipLaunchKernelGGL(k_wide, dim3(grid), dim3(kThreads), 0, stream, d_nodes, n_nodes, d_wide);
+}
 
 int build_bvh_device(hipStream_t stream, const BuildBox *h_boxes, uint32_t n, uint32_t sphere_begin, uint32_t sphere_end,
                      Node *d_nodes, uint32_t *h_order, uint32_t *depth, std::string &err) {

@@ -37,7 +37,11 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 // All bounces of a batch in one launch (k_paths); `counts` / `early` rows 1 .. max_depth must be zero.
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves);
+                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves, bool stack, const StackSpill &spill);
+// `stack`: traverse the 64-byte node records with a per-lane stack (sc.wide must be set; `lds_bytes`, when not
+// zero, then counts those records + the primitives + 16 bytes).  The stack keeps kStackEntriesInLds entries per
+// lane in LDS (added to the launch's LDS size here) and the rest in `spill`.
+constexpr int kStackEntriesInLds = 8;
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals);
 

@@ -82,9 +82,7 @@ struct Closest {
 
 // TriangleRef::hit up to the range test (src/object/triangle_mesh.rs:140-170): Möller–Trumbore without
 // culling, `contains` is inclusive at both ends.
-__device__ __forceinline__ void tri_test(const float4 *__restrict__ prim, uint32_t slot, V3 o, V3 d, float tmin,
-                                         Closest &best) {
-    float4 a = prim[0], b = prim[1], c = prim[2];
+__device__ __forceinline__ void tri_test(float4 a, float4 b, float4 c, uint32_t slot, V3 o, V3 d, float tmin, Closest &best) {
     V3 v0 = xyz(a), e1 = xyz(b), e2 = xyz(c);
     V3 p = cross(d, e2);
     float det = dot(e1, p);
@@ -104,10 +102,13 @@ __device__ __forceinline__ void tri_test(const float4 *__restrict__ prim, uint32
     best.v = v;
 }
 
+__device__ __forceinline__ void tri_test(const float4 *__restrict__ prim, uint32_t slot, V3 o, V3 d, float tmin,
+                                         Closest &best) {
+    tri_test(prim[0], prim[1], prim[2], slot, o, d, tmin, best);
+}
+
 // Sphere::hit up to the range test (src/object/sphere.rs:55-72): `surrounds` is exclusive.
-__device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uint32_t slot, V3 o, V3 d, float tmin,
-                                            Closest &best) {
-    float4 a = prim[0];
+__device__ __forceinline__ void sphere_test(float4 a, uint32_t slot, V3 o, V3 d, float tmin, Closest &best) {
     V3 oc = xyz(a) - o;
     float aa = length_squared(d);
     float h = dot(d, oc);
@@ -124,6 +125,11 @@ __device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uin
     best.slot = slot | kSphereBit;
     best.u = 0.0f;
     best.v = 0.0f;
+}
+
+__device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uint32_t slot, V3 o, V3 d, float tmin,
+                                            Closest &best) {
+    sphere_test(prim[0], slot, o, d, tmin, best);
 }
 
 // BvhNode::hit (src/bvh.rs:295-317) as a stackless pre-order walk.  `best.t` plays the role of the
@@ -176,6 +182,117 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
             sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
         else
             tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BvhNode::hit with the child boxes stored in the parent (WideNode, rt_device.h) and a per-lane stack.
+//
+// Aabb::hit narrows [lo, hi] = [t_min, closest so far] by the three slabs and reports a hit unless hi <= lo.
+// The slabs' contribution does not depend on the closest distance: with E = max(t_min, the three entry
+// distances) and X = min(the three exit distances) (NaNs dropped as the compare-and-assign form drops them) the
+// box is hit iff !(min(closest, X) <= E).  So both children's (E, X) are computed when their parent is entered:
+// the left child is decided at once (nothing happens between the parent's and its visit), the right child is
+// pushed as (E, reference) if it passes with the present closest distance, and decided again when it is popped,
+// with the closest distance of that moment, which is exactly when and with what BvhNode::hit tests it.  Since the
+// closest distance only shrinks, a right child that fails at push time would fail later too, and one that passed
+// (so X > E) passes later iff closest > E: the stack entry needs E only.  Visiting order, primitive tests and
+// every comparison are the reference's; what changes is that a node whose box is missed costs no memory access
+// and an entered node costs one 64-byte read.
+//
+// The stack: the K most recent entries live in LDS (entry e of a thread at lds[(e % K) * THREADS]), older ones
+// are moved to `spill` in device memory and come back when the LDS part runs empty.  At most depth - 1 entries
+// exist at a time.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab_pair(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, V3 o, V3 inv,
+                                          float tmin, float &E, float &X) {
+    v2f tx = (v2f{xlo, xhi} - v2f{o.x, o.x}) * v2f{inv.x, inv.x};
+    v2f ty = (v2f{ylo, yhi} - v2f{o.y, o.y}) * v2f{inv.y, inv.y};
+    v2f tz = (v2f{zlo, zhi} - v2f{o.z, o.z}) * v2f{inv.z, inv.z};
+    bool s = tx.x < tx.y;
+    float lo = max_raw(tmin, s ? tx.x : tx.y);
+    float hi = s ? tx.y : tx.x;
+    hi = (hi != hi) ? __builtin_inff() : hi; // a NaN exit distance leaves the interval as it is
+    s = ty.x < ty.y;
+    lo = max_raw(lo, s ? ty.x : ty.y);
+    hi = min_raw(hi, s ? ty.y : ty.x);
+    s = tz.x < tz.y;
+    lo = max_raw(lo, s ? tz.x : tz.y);
+    hi = min_raw(hi, s ? tz.y : tz.x);
+    E = lo;
+    X = hi;
+}
+
+template <int K, int THREADS>
+struct LaneStack {
+    uint2 *lds;    // this thread's column of the block's LDS stack area
+    uint2 *spill;  // this thread's column of the spill area
+    uint32_t stride;
+    uint32_t sp = 0, lo = 0; // entries [lo, sp) are in LDS, [0, lo) in the spill area
+    __device__ __forceinline__ void push(float e, uint32_t ref) {
+        if (sp - lo == (uint32_t)K) {
+            spill[(size_t)lo * stride] = lds[(lo & (K - 1)) * THREADS];
+            ++lo;
+        }
+        lds[(sp & (K - 1)) * THREADS] = make_uint2(f2u(e), ref);
+        ++sp;
+    }
+    __device__ __forceinline__ uint2 pop() {
+        --sp;
+        if (sp < lo) {
+            lo = sp;
+            return spill[(size_t)sp * stride];
+        }
+        return lds[(sp & (K - 1)) * THREADS];
+    }
+};
+
+template <int K, int THREADS>
+__device__ __forceinline__ Closest traverse_stack(const float4 *__restrict__ wide, const float4 *__restrict__ prims,
+                                                  float4 root_lo, float4 root_hi, uint32_t root_ref, V3 o, V3 d, float tmin,
+                                                  float tmax, uint2 *lds_stack, StackSpill spill) {
+    const V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    tmin = in_vgpr(tmin);
+    LaneStack<K, THREADS> stack;
+    stack.lds = lds_stack + threadIdx.x;
+    stack.spill = spill.spill + (size_t)blockIdx.x * THREADS + threadIdx.x;
+    stack.stride = spill.stride;
+    float E, X;
+    slab_pair(root_lo.x, root_lo.y, root_lo.z, root_lo.w, root_hi.x, root_hi.y, o, inv, tmin, E, X);
+    uint32_t cur = !(min_raw(best.t, X) <= E) ? root_ref : kRefNone;
+    while (cur != kRefNone) {
+        const bool leaf = (cur & kRefLeaf) != 0u;
+        const uint32_t index = cur & kRefIndex;
+        // one memory round per step whatever the lanes hold: 64 bytes of a node record, or the 48 bytes of a
+        // primitive (the fourth quad is then the head of the next record; the tables are padded for it)
+        const float4 *__restrict__ p = leaf ? prims + 3 * (size_t)index : wide + 4 * (size_t)index;
+        const float4 a = p[0], b = p[1], c = p[2], q = p[3];
+        uint32_t next = kRefNone;
+        if (leaf) {
+            if (cur & kRefSphere)
+                sphere_test(a, index, o, d, tmin, best);
+            else
+                tri_test(a, b, c, index, o, d, tmin, best);
+        } else {
+            float el, xl, er, xr;
+            slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, el, xl);
+            slab_pair(c.x, c.y, c.z, c.w, b.z, b.w, o, inv, tmin, er, xr);
+            const bool hit_l = !(min_raw(best.t, xl) <= el);
+            const bool hit_r = !(min_raw(best.t, xr) <= er);
+            if (hit_l) {
+                next = f2u(q.x);
+                if (hit_r) stack.push(er, f2u(q.y));
+            } else if (hit_r) {
+                next = f2u(q.y);
+            }
+        }
+        while (next == kRefNone && stack.sp > 0u) {
+            const uint2 e = stack.pop();
+            if (!(best.t <= u2f(e.x))) next = e.y;
+        }
+        cur = next;
     }
     return best;
 }
@@ -520,6 +637,19 @@ __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *l
     prims = lds + n4_nodes;
 }
 
+// The same for the stack traversal: node records (WideNode) + primitives, followed by one spare quad (a leaf step
+// reads four quads of a three-quad primitive record).  Returns the first quad after the copy.
+__device__ __forceinline__ float4 *stage_wide_scene_in_lds(const SceneDev &sc, float4 *lds, const float4 *&wide,
+                                                           const float4 *&prims) {
+    const uint32_t n4_wide = 4u * (sc.n_prims - 1u), n4_prims = 3u * sc.n_prims;
+    for (uint32_t i = threadIdx.x; i < n4_wide; i += blockDim.x) lds[i] = wide[i];
+    for (uint32_t i = threadIdx.x; i < n4_prims; i += blockDim.x) lds[n4_wide + i] = prims[i];
+    if (threadIdx.x == 0) lds[n4_wide + n4_prims] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    wide = lds;
+    prims = lds + n4_wide;
+    return lds + n4_wide + n4_prims + 1u;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // extend: closest hit of every queued ray.
 //
@@ -850,16 +980,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
 // WAVES: waves per SIMD the register budget is set for.  Six fit without spilling and suit scenes served by LDS
 // or the caches; scenes read from HBM gain more from eight waves in flight than the few spilled registers cost.
 // HAS_MIX: the scene holds Mix materials (evaluated by scatter_material instead of scatter_leaf).
-template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false>
+// STACK: 0 = the stackless walk over the 32-byte node table (traverse); K > 0 = the stack traversal over the 64-byte
+// records with K stack entries per lane in LDS (traverse_stack).
+template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false, int STACK = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREADS == kBlock && !HAS_MIX) ? WAVES : 4))) void k_paths(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
-    uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
+    uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early, StackSpill spill) {
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_out, s_early, s_next;
-    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *nodes = reinterpret_cast<const float4 *>(STACK ? static_cast<const void *>(sc.wide) : static_cast<const void *>(sc.nodes));
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
-    const float4 root_lo = nodes[0], root_hi = nodes[1];
-    if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
+    const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
+    uint2 *lds_stack = reinterpret_cast<uint2 *>(s_scene);
+    if (LDS_SCENE) {
+        if (STACK)
+            lds_stack = reinterpret_cast<uint2 *>(stage_wide_scene_in_lds(sc, s_scene, nodes, prims));
+        else
+            stage_scene_in_lds(sc, s_scene, nodes, prims);
+    }
+    auto closest_hit = [&](V3 o, V3 d) {
+        if constexpr (STACK != 0) {
+            return traverse_stack<(STACK ? STACK : 1), THREADS>(nodes, prims, root_lo, root_hi, sc.root_ref, o, d, P.z_near, P.z_far,
+                                                               lds_stack, spill);
+        } else {
+            uint32_t c0 = 0, c1 = 0, c2 = 0;
+            return traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+        }
+    };
     if (threadIdx.x == 0) {
         s_out = 0u;
         s_early = 0u;
@@ -868,7 +1015,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t seg = blockIdx.x * cap;
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
 
     // Within a bounce the block's waves claim 64 items at a time from a shared cursor, so a wave that drew
     // long traversals does not leave the others waiting at the end of the bounce.
@@ -887,7 +1033,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
             V3 o, d;
             uint32_t s_local, pixel;
             const uint32_t k = generate_ray(P, slot, o, d, s_local, pixel);
-            Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+            Closest best = closest_hit(o, d);
             alive = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, V3{1.0f, 1.0f, 1.0f}, k, 0u, 0u,
                                                  s_local, pixel, best);
         }
@@ -923,7 +1069,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
                 const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
                 const V3 o = xyz(o4), d = xyz(d4);
                 const uint32_t s_local = f2u(d4.w) >> 16;
-                Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+                Closest best = closest_hit(o, d);
                 alive = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, xyz(st.beta[slot]),
                                                      f2u(o4.w) & kDrawMask, f2u(o4.w) >> kDrawBits, f2u(d4.w) & 0xFFFFu, s_local,
                                                      slot - s_local * P.npix, best);
@@ -1081,24 +1227,38 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves) {
-    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *);
+                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves, bool stack, const StackSpill &spill) {
+    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, StackSpill);
     Kernel kernel;
     uint32_t threads = kBlock;
+    constexpr int K = kStackEntriesInLds;
     // Scenes with Mix materials use the instances that also interpolate texture coordinates.
     if (!lds_bytes && eight_waves) {
-        kernel = has_mix ? k_paths<false, true, kBlock, 8, true> : need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
+        if (stack)
+            kernel = has_mix ? k_paths<false, true, kBlock, 8, true, K> : need_uv ? k_paths<false, true, kBlock, 8, false, K> : k_paths<false, false, kBlock, 8, false, K>;
+        else
+            kernel = has_mix ? k_paths<false, true, kBlock, 8, true> : need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
     } else if (lds_bytes && big_blocks) {
-        kernel = has_mix ? k_paths<true, true, 1024, 6, true> : need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
+        if (stack)
+            kernel = has_mix ? k_paths<true, true, 1024, 6, true, K> : need_uv ? k_paths<true, true, 1024, 6, false, K> : k_paths<true, false, 1024, 6, false, K>;
+        else
+            kernel = has_mix ? k_paths<true, true, 1024, 6, true> : need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
         threads = 1024;
-        if (lds_bytes > 48u * 1024u)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     } else if (lds_bytes) {
-        kernel = has_mix ? k_paths<true, true, kBlock, 6, true> : need_uv ? k_paths<true, true> : k_paths<true, false>;
+        if (stack)
+            kernel = has_mix ? k_paths<true, true, kBlock, 6, true, K> : need_uv ? k_paths<true, true, kBlock, 6, false, K> : k_paths<true, false, kBlock, 6, false, K>;
+        else
+            kernel = has_mix ? k_paths<true, true, kBlock, 6, true> : need_uv ? k_paths<true, true> : k_paths<true, false>;
     } else {
-        kernel = has_mix ? k_paths<false, true, kBlock, 6, true> : need_uv ? k_paths<false, true> : k_paths<false, false>;
+        if (stack)
+            kernel = has_mix ? k_paths<false, true, kBlock, 6, true, K> : need_uv ? k_paths<false, true, kBlock, 6, false, K> : k_paths<false, false, kBlock, 6, false, K>;
+        else
+            kernel = has_mix ? k_paths<false, true, kBlock, 6, true> : need_uv ? k_paths<false, true> : k_paths<false, false>;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
+    if (stack) lds_bytes += (uint32_t)(K * threads * sizeof(uint2));
+    if (lds_bytes > 48u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early, spill);
 }
 
 // ------------------------------------------------------------------------------------------------------

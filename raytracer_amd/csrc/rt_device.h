@@ -30,6 +30,27 @@ struct alignas(16) Node {
 };
 static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 
+// The same tree once more with the boxes of a node's two children stored in the node: one 64-byte record per
+// INTERIOR node, in pre-order over the interior nodes (so a left child that is interior is the next record).
+// BvhNode::hit tests both children's boxes whenever it enters a node (src/bvh.rs:302-313), so a record is read
+// whole: one 64-byte fetch per entered node instead of one 32-byte fetch per box test, and leaves need no node
+// record at all (the child reference names the primitive).
+//   q0 = left.xlo, left.xhi, left.ylo, left.yhi      q1 = left.zlo, left.zhi, right.zlo, right.zhi
+//   q2 = right.xlo, right.xhi, right.ylo, right.yhi  q3 = left ref, right ref, 0, 0
+// A child reference is the index of an interior record, or kRefLeaf | slot in the primitive table
+// (| kRefSphere for a sphere).
+struct alignas(64) WideNode {
+    float lx[2], ly[2];
+    float lz[2], rz[2];
+    float rx[2], ry[2];
+    uint32_t left, right, pad[2];
+};
+static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+constexpr uint32_t kRefLeaf = 0x80000000u;
+constexpr uint32_t kRefSphere = 0x40000000u;
+constexpr uint32_t kRefIndex = 0x3FFFFFFFu;
+constexpr uint32_t kRefNone = 0xFFFFFFFFu;
+
 // An object's own bounding box (`Hittable::bounding_box`), already padded; input of the tree builders.
 struct BuildBox {
     float lo[3];
@@ -99,6 +120,9 @@ struct SceneDev {
     const TextureRec *textures;
     const uint8_t *texels;
     const uint32_t *slot_of_prim; // primitive ID -> slot in `prims` (object-list order for World::hit)
+    const WideNode *wide;         // n_prims - 1 records; nullptr when the table was not built
+    uint32_t root_ref;            // child reference of the root (a leaf reference for a one-primitive scene)
+    uint32_t depth;               // levels of the tree: the traversal stack never holds more than depth - 1 entries
     uint32_t n_nodes;
     uint32_t n_prims;
     uint32_t n_materials;
@@ -148,6 +172,13 @@ struct QueueView {
     const uint32_t *counts;
     uint32_t cap;
     uint32_t n;
+};
+
+// Memory of the per-lane traversal stacks beyond their LDS part: entry e of thread t (numbered over the whole
+// grid) is spill[e * stride + t].
+struct StackSpill {
+    uint2 *spill;
+    uint32_t stride;
 };
 
 struct ExtendCounters {
