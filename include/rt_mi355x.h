@@ -279,6 +279,10 @@ int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
  *   PATHS   one kernel launch per batch: every block generates its share of camera rays and then keeps
  *           bouncing its own survivors (a block only consumes the queue segment it produced, so no grid-wide
  *           synchronisation is needed between bounces)
+ *   LANES   one kernel launch per batch with one lane per PATH: a lane keeps its path in registers from the
+ *           camera ray to its end, is shaded where it is when its walk finishes and takes the next path of its
+ *           block's share when the path ends; no queues and no path state in device memory.  For scenes read from
+ *           HBM, where walks are chains of dependent fetches of very uneven length.
  *   AUTO    PATHS_LDS when the tables fit in 150 KB of LDS (256-thread blocks up to 40 KB, above that one
  *           1024-thread block per CU shares the copy), else PATHS: the fastest measured on every scene.  The other
  *           *_LDS pipelines take tables up to 64 KB. */
@@ -291,7 +295,8 @@ enum {
     RT_PIPELINE_HYBRID_LDS = 5,
     RT_PIPELINE_SPLIT_LDS = 6,
     RT_PIPELINE_PATHS = 7,
-    RT_PIPELINE_PATHS_LDS = 8
+    RT_PIPELINE_PATHS_LDS = 8,
+    RT_PIPELINE_LANES = 9
 };
 int rt_context_set_pipeline(rt_context *ctx, uint32_t pipeline);
 /* With RT_CTX_TIMING, bracket only the launches of the first `bounces` bounces of every batch with events

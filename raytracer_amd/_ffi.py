@@ -28,7 +28,7 @@ RT_MISS = 0xFFFFFFFF
 RT_NOALLOC_MAX_RAYS = 65536
 RT_CTX_TIMING, RT_CTX_COUNTERS = 1, 2
 (RT_PIPELINE_AUTO, RT_PIPELINE_SPLIT, RT_PIPELINE_FUSED, RT_PIPELINE_FUSED_LDS, RT_PIPELINE_HYBRID,
- RT_PIPELINE_HYBRID_LDS, RT_PIPELINE_SPLIT_LDS, RT_PIPELINE_PATHS, RT_PIPELINE_PATHS_LDS) = range(9)
+ RT_PIPELINE_HYBRID_LDS, RT_PIPELINE_SPLIT_LDS, RT_PIPELINE_PATHS, RT_PIPELINE_PATHS_LDS, RT_PIPELINE_LANES) = range(10)
 
 _f3 = C.c_float * 3
 

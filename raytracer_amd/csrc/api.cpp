@@ -94,6 +94,8 @@ struct rt_context {
     uint64_t max_paths = 1ull << 26;
     uint32_t timed_bounces = 0xFFFFFFFFu;
     uint32_t pipeline = RT_PIPELINE_AUTO;
+    bool lanes_lockstep_first = true; // LANES: camera rays in lockstep first (environment variable RT_LANES_FIRST=lanes turns it off)
+    int lanes_waves = 4;              // waves per SIMD of the LANES kernel (environment variable RT_LANES_WAVES)
     int traversal = 0;                // -1 walk, +1 stack, 0 = chosen per scene (environment variable RT_TRAVERSAL)
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
@@ -259,6 +261,11 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
     }
     if (const char *e = std::getenv("RT_TRAVERSAL")) // tuning knob for experiments: "walk" or "stack"
         c->traversal = !std::strcmp(e, "walk") ? -1 : !std::strcmp(e, "stack") ? 1 : 0;
+    if (const char *e = std::getenv("RT_LANES_FIRST")) c->lanes_lockstep_first = std::strcmp(e, "lanes") != 0;
+    if (const char *e = std::getenv("RT_LANES_WAVES")) {
+        long v = std::strtol(e, nullptr, 10);
+        if (v == 4 || v == 6 || v == 8) c->lanes_waves = (int)v;
+    }
     c->cus = (uint32_t)std::max(1, prop.multiProcessorCount);
     c->max_blocks = c->cus * 8u;
     if (stream) {
@@ -323,7 +330,7 @@ RT_API int rt_context_synchronize(rt_context *c) {
 
 RT_API int rt_context_set_pipeline(rt_context *c, uint32_t pipeline) {
     if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "null context");
-    if (pipeline > RT_PIPELINE_PATHS_LDS) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown pipeline %u", pipeline);
+    if (pipeline > RT_PIPELINE_LANES) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown pipeline %u", pipeline);
     c->pipeline = pipeline;
     return RT_OK;
 }
@@ -674,21 +681,23 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         if (c->pipeline == RT_PIPELINE_AUTO && table_bytes > 64u * 1024u) lds = false;
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     }
-    if (s->has_mix && pipeline != RT_PIPELINE_PATHS && pipeline != RT_PIPELINE_PATHS_LDS)
+    if (pipeline == RT_PIPELINE_LANES && !s->dev.wide) pipeline = RT_PIPELINE_PATHS;
+    const bool lanes = pipeline == RT_PIPELINE_LANES;
+    if (s->has_mix && pipeline != RT_PIPELINE_PATHS && pipeline != RT_PIPELINE_PATHS_LDS && !lanes)
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     const bool big_blocks = pipeline == RT_PIPELINE_PATHS_LDS && table_bytes > 40u * 1024u;
     if (lds && table_bytes > (big_blocks ? 150u : 64u) * 1024u)
         return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
                          (unsigned long long)table_bytes);
-    const bool paths = pipeline == RT_PIPELINE_PATHS || pipeline == RT_PIPELINE_PATHS_LDS;
+    const bool paths = pipeline == RT_PIPELINE_PATHS || pipeline == RT_PIPELINE_PATHS_LDS || lanes;
     const bool fused_all = paths || pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
     const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
     // Traversal of the PATHS kernels: the stack traversal over 64-byte records, or the stackless walk over the
     // 32-byte node table.
     const uint64_t wide_table_bytes = (uint64_t)(s->dev.n_prims - 1u) * sizeof(rt::WideNode) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim) + 16u;
     const uint64_t stack_lds_bytes = (uint64_t)rt::kStackEntriesInLds * (big_blocks ? 1024u : 256u) * sizeof(uint2);
-    const bool stack = paths && s->dev.wide && (c->traversal > 0 || (c->traversal == 0 && !lds)) &&
-                       (!lds || wide_table_bytes + stack_lds_bytes <= 159u * 1024u);
+    const bool stack = lanes || (paths && s->dev.wide && (c->traversal > 0 || (c->traversal == 0 && !lds)) &&
+                       (!lds || wide_table_bytes + stack_lds_bytes <= 159u * 1024u));
     const uint32_t lds_bytes = lds ? (uint32_t)(stack ? wide_table_bytes : table_bytes) : 0u;
     // One grid for every bounce of a batch: block b owns segment b of both queues (see QueueView).
     const uint32_t chunks = (uint32_t)((slots + 255) / 256);
@@ -700,12 +709,20 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // of that latency than six; 10 M soup 0.286 -> 0.325 Grays/s, while the L2-resident teapot loses 2 % with them.
     const bool eight_waves = pipeline == RT_PIPELINE_PATHS && table_bytes > (16u << 20);
     const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu
+                                   : lanes         ? (uint32_t)(s->has_mix ? 4 : c->lanes_waves) // one resident round
                                    : big_blocks    ? 1u
                                    : eight_waves   ? 8u
                                                    : (table_bytes <= 256u * 1024u ? 24u : 6u);
     const uint32_t grid = std::min(c->cus * blocks_per_cu, chunks);
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
-    if (int rc = ensure_render(c, slots, (size_t)grid * cap, st->max_depth, grid)) return rc;
+    if (int rc = ensure_render(c, lanes ? 0 : slots, lanes ? 0 : (size_t)grid * cap, st->max_depth, grid)) return rc;
+    if (int rc = c->radiance.ensure(slots)) return rc;
+    if (lanes && c->lanes_lockstep_first) { // survivors of bounce 0 pass through device memory once
+        if (int rc = c->ray_o.ensure(slots)) return rc;
+        if (int rc = c->ray_d.ensure(slots)) return rc;
+        if (int rc = c->beta.ensure(slots)) return rc;
+        if (int rc = c->queue[0].ensure((size_t)grid * cap)) return rc;
+    }
     const uint32_t block_threads = big_blocks ? 1024u : 256u;
     rt::StackSpill spill{nullptr, grid * block_threads};
     if (stack) {
@@ -758,8 +775,12 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             HIP_TRY(hipMemsetAsync(c->counts.ptr + grid, 0, rows, c->stream));
             HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
-            rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr, c->early.ptr,
-                             s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves, stack, spill);
+            if (lanes)
+                rt::launch_paths_lanes(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->counts.ptr + grid, s->need_uv,
+                                       s->has_mix, c->lanes_waves, spill, c->lanes_lockstep_first);
+            else
+                rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr,
+                                 c->early.ptr, s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves, stack, spill);
             if (int rc = timed_end(c)) return rc;
             ++bounce_launches;
         }

@@ -248,21 +248,33 @@ struct LaneStack {
     }
 };
 
+// One ray's walk: begin() tests the root box (BvhNode::hit on the root), step() handles the node or primitive
+// `cur` names and moves to the next one in the reference's order; the walk is over when cur == kRefNone.
 template <int K, int THREADS>
-__device__ __forceinline__ Closest traverse_stack(const float4 *__restrict__ wide, const float4 *__restrict__ prims,
-                                                  float4 root_lo, float4 root_hi, uint32_t root_ref, V3 o, V3 d, float tmin,
-                                                  float tmax, uint2 *lds_stack, StackSpill spill) {
-    const V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
-    tmin = in_vgpr(tmin);
+struct StackWalk {
     LaneStack<K, THREADS> stack;
-    stack.lds = lds_stack + threadIdx.x;
-    stack.spill = spill.spill + (size_t)blockIdx.x * THREADS + threadIdx.x;
-    stack.stride = spill.stride;
-    float E, X;
-    slab_pair(root_lo.x, root_lo.y, root_lo.z, root_lo.w, root_hi.x, root_hi.y, o, inv, tmin, E, X);
-    uint32_t cur = !(min_raw(best.t, X) <= E) ? root_ref : kRefNone;
-    while (cur != kRefNone) {
+    V3 o, d, inv;
+    float tmin;
+    Closest best;
+    uint32_t cur;
+
+    __device__ __forceinline__ void init(uint2 *lds_stack, const StackSpill &spill) {
+        stack.lds = lds_stack + threadIdx.x;
+        stack.spill = spill.spill + (size_t)blockIdx.x * THREADS + threadIdx.x;
+        stack.stride = spill.stride;
+        cur = kRefNone;
+    }
+    __device__ __forceinline__ void begin(float4 root_lo, float4 root_hi, uint32_t root_ref, V3 origin, V3 dir, float t_min, float t_max) {
+        o = origin;
+        d = dir;
+        inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+        best = Closest{t_max, kMissSlot, 0.0f, 0.0f};
+        tmin = in_vgpr(t_min);
+        float E, X;
+        slab_pair(root_lo.x, root_lo.y, root_lo.z, root_lo.w, root_hi.x, root_hi.y, o, inv, tmin, E, X);
+        cur = !(min_raw(best.t, X) <= E) ? root_ref : kRefNone;
+    }
+    __device__ __forceinline__ void step(const float4 *__restrict__ wide, const float4 *__restrict__ prims) {
         const bool leaf = (cur & kRefLeaf) != 0u;
         const uint32_t index = cur & kRefIndex;
         // one memory round per step whatever the lanes hold: 64 bytes of a node record, or the 48 bytes of a
@@ -294,7 +306,17 @@ __device__ __forceinline__ Closest traverse_stack(const float4 *__restrict__ wid
         }
         cur = next;
     }
-    return best;
+};
+
+template <int K, int THREADS>
+__device__ __forceinline__ Closest traverse_stack(const float4 *__restrict__ wide, const float4 *__restrict__ prims,
+                                                  float4 root_lo, float4 root_hi, uint32_t root_ref, V3 o, V3 d, float tmin,
+                                                  float tmax, uint2 *lds_stack, StackSpill spill) {
+    StackWalk<K, THREADS> walk;
+    walk.init(lds_stack, spill);
+    walk.begin(root_lo, root_hi, root_ref, o, d, tmin, tmax);
+    while (walk.cur != kRefNone) walk.step(wide, prims);
+    return walk.best;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -798,33 +820,41 @@ __global__ __launch_bounds__(kBlock) void k_extend_world(SceneDev sc, const floa
 // returns kPathEndedByEarlyMiss so the caller can still count the ray; the sums are unchanged.
 enum : int { kPathEnded = 0, kPathAlive = 1, kPathEndedByEarlyMiss = 2 };
 
+// The segment of a path that is being traced: its ray, throughput, the index of its next random draw, the NaN
+// flags of its radiance so far and its depth.
+struct Segment {
+    V3 o, d, beta;
+    uint32_t k, flags, depth;
+};
+
+// Shades the hit `best` of segment `g`.  Returns kPathAlive with `g` replaced by the path's next segment, or one
+// of the two ended outcomes with the path's final radiance in `l`.
 template <bool NEED_UV, bool HAS_MIX>
-__device__ __forceinline__ int shade_path(const SceneDev &sc, float4 root_lo, float4 root_hi,
-                                          const float4 *__restrict__ prims, const RenderParams &P, const PathState &st,
-                                          uint32_t slot, V3 o, V3 d, V3 beta, uint32_t k, uint32_t flags, uint32_t depth,
-                                          uint32_t s_local, uint32_t pixel, const Closest &best) {
+__device__ __forceinline__ int shade_segment(const SceneDev &sc, float4 root_lo, float4 root_hi,
+                                             const float4 *__restrict__ prims, const RenderParams &P, Segment &g,
+                                             uint32_t s_local, uint32_t pixel, const Closest &best, V3 &l) {
     bool alive = false;
     bool early_miss = false;
     const float qnan = __builtin_nanf("");
-    V3 l = V3{(flags & 1u) ? qnan : 0.0f, (flags & 2u) ? qnan : 0.0f, (flags & 4u) ? qnan : 0.0f};
+    l = V3{(g.flags & 1u) ? qnan : 0.0f, (g.flags & 2u) ? qnan : 0.0f, (g.flags & 4u) ? qnan : 0.0f};
     if (best.slot == kMissSlot) {
         l = ld3(P.background); // src/renderer.rs:59-63: the background REPLACES the radiance gathered so far
     } else {
-        Surface s = make_surface<NEED_UV>(sc, prims, o, d, best.t, best.slot, best.u, best.v);
+        Surface s = make_surface<NEED_UV>(sc, prims, g.o, g.d, best.t, best.slot, best.u, best.v);
         const MaterialRec m = sc.materials[s.material];
         // src/renderer.rs:48: l += beta * emit.  Non-emitters contribute beta * 0, which is NaN once beta holds
         // an infinity, exactly as in the reference.
         V3 emit = V3{0.0f, 0.0f, 0.0f};
         if (m.kind == 3u) emit = material_color(sc, m, s) * m.param;
-        l = l + beta * emit;
-        Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, k);
+        l = l + g.beta * emit;
+        Rng rng = rng_for_path(P.seed_mix, pixel, P.sample_base + s_local, g.k);
         Scatter sr;
-        const bool scattered = HAS_MIX ? scatter_material<4>(sc, (int32_t)s.material, d, s, rng, sr)
-                                       : scatter_leaf(sc, m, d, s, rng, sr);
+        const bool scattered = HAS_MIX ? scatter_material<4>(sc, (int32_t)s.material, g.d, s, rng, sr)
+                                       : scatter_leaf(sc, m, g.d, s, rng, sr);
         if (scattered) {
             V3 f = (sr.attenuation * fabsf(dot(sr.direction, s.normal))) / sr.pdf; // src/renderer.rs:51-54
-            beta = beta * f;
-            depth += 1u;
+            V3 beta = g.beta * f;
+            const uint32_t depth = g.depth + 1u;
             // src/renderer.rs:39-41: `while beta != 0` then `depth >= max_depth`
             alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
             if (alive) {
@@ -838,15 +868,35 @@ __device__ __forceinline__ int shade_path(const SceneDev &sc, float4 root_lo, fl
             }
             if (alive) {
                 // a scattering material emits nothing, so l is still +0 or NaN per channel here
-                flags = (l.x != l.x ? 1u : 0u) | (l.y != l.y ? 2u : 0u) | (l.z != l.z ? 4u : 0u);
-                st.ray_o[slot] = mk4(s.point, u2f((rng.k & kDrawMask) | (flags << kDrawBits)));
-                st.ray_d[slot] = mk4(sr.direction, u2f((s_local << 16) | depth));
-                st.beta[slot] = mk4(beta, 0.0f);
+                g.flags = (l.x != l.x ? 1u : 0u) | (l.y != l.y ? 2u : 0u) | (l.z != l.z ? 4u : 0u);
+                g.o = s.point;
+                g.d = sr.direction;
+                g.beta = beta;
+                g.k = rng.k;
+                g.depth = depth;
             }
         }
     }
-    if (!alive) st.radiance[slot] = mk4(l, 0.0f);
     return alive ? kPathAlive : (early_miss ? kPathEndedByEarlyMiss : kPathEnded);
+}
+
+// The same with the path's state kept in device memory: stores the next segment, or the final radiance.
+template <bool NEED_UV, bool HAS_MIX>
+__device__ __forceinline__ int shade_path(const SceneDev &sc, float4 root_lo, float4 root_hi,
+                                          const float4 *__restrict__ prims, const RenderParams &P, const PathState &st,
+                                          uint32_t slot, V3 o, V3 d, V3 beta, uint32_t k, uint32_t flags, uint32_t depth,
+                                          uint32_t s_local, uint32_t pixel, const Closest &best) {
+    Segment g{o, d, beta, k, flags, depth};
+    V3 l;
+    const int outcome = shade_segment<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, g, s_local, pixel, best, l);
+    if (outcome == kPathAlive) {
+        st.ray_o[slot] = mk4(g.o, u2f((g.k & kDrawMask) | (g.flags << kDrawBits)));
+        st.ray_d[slot] = mk4(g.d, u2f((s_local << 16) | g.depth));
+        st.beta[slot] = mk4(g.beta, 0.0f);
+    } else {
+        st.radiance[slot] = mk4(l, 0.0f);
+    }
+    return outcome;
 }
 
 // Appends the surviving lanes' slots to the block's output segment: ranks from ballot + popcount, one LDS
@@ -1079,6 +1129,151 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// paths, one lane per path: for scenes read from HBM.  There a ray's walk is a chain of dependent fetches whose
+// length varies several-fold from ray to ray, so a wave that starts 64 rays together and waits for the longest
+// keeps a sixth of its lanes busy.  Here a lane owns a PATH and keeps it in registers from the camera ray to its
+// end: when enough of a wave's lanes have finished their walk they are shaded where they are and start their
+// next segment at once; lanes whose path has ended take the next path of the block's share of the batch.  No
+// queue, no path state in device memory: only the final radiance is written.  Samples are still added per pixel
+// in sample order by k_accumulate, so the sums do not depend on which lane traced what.
+// `ray_counts[b]`: rays beyond the first of each path that block b traced (settled early misses included).
+// ------------------------------------------------------------------------------------------------------
+template <bool NEED_UV, bool HAS_MIX, int WAVES, int K>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : WAVES))) void k_paths_lanes(
+    SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue,
+    uint32_t *__restrict__ ray_counts, StackSpill spill, uint32_t camera_rays_in_lockstep) {
+    extern __shared__ float4 s_scene[];
+    __shared__ uint32_t s_next, s_rays, s_out, s_early;
+    const float4 *__restrict__ wide = reinterpret_cast<const float4 *>(sc.wide);
+    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
+    const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
+    if (threadIdx.x == 0) {
+        s_next = 0u;
+        s_rays = 0u;
+        s_out = 0u;
+        s_early = 0u;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t seg = blockIdx.x * cap;
+    // the block's share of the batch: its round-robin 256-slot chunks
+    const uint32_t chunks = (n_slots + kBlock - 1) / kBlock;
+    uint32_t my_items = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
+
+    StackWalk<K, kBlock> walk;
+    walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
+    Segment g{};
+    uint32_t slot = 0, s_local = 0, pixel = 0, n_rays = 0;
+
+    // Camera rays first, 64 neighbouring pixels per wave in lockstep: their walks touch the same nodes, which the
+    // vector cache then fetches once per wave.  Survivors go to the block's queue segment with their state.
+    const bool from_queue = camera_rays_in_lockstep != 0u;
+    if (from_queue) {
+        const uint32_t my_quarters = my_items / 64u;
+        for (;;) {
+            uint32_t quarter = 0;
+            if (lane == 0) quarter = atomicAdd(&s_next, 1u);
+            quarter = __shfl(quarter, 0);
+            if (quarter >= my_quarters) break;
+            slot = ((quarter >> 2) * gridDim.x + blockIdx.x) * kBlock + (quarter & 3u) * 64u + lane;
+            int outcome = kPathEnded;
+            if (slot < n_slots) {
+                V3 o, d;
+                const uint32_t k = generate_ray(P, slot, o, d, s_local, pixel);
+                walk.begin(root_lo, root_hi, sc.root_ref, o, d, P.z_near, P.z_far);
+                while (walk.cur != kRefNone) walk.step(wide, prims);
+                outcome = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, V3{1.0f, 1.0f, 1.0f}, k, 0u, 0u,
+                                                       s_local, pixel, walk.best);
+            }
+            compact_survivors(outcome, slot, lane, &s_out, &s_early, queue, seg);
+        }
+        __syncthreads(); // the appends and the state behind them are complete and visible
+        my_items = s_out;
+        if (threadIdx.x == 0) {
+            s_next = 0u;
+            s_rays = s_early;
+        }
+        __syncthreads();
+    }
+
+    bool have = false, exhausted = false;
+    walk.cur = kRefNone;
+    for (;;) {
+        const bool finished = have && walk.cur == kRefNone;
+        const uint32_t n_fin = __popcll(__ballot(finished));
+        const uint32_t n_empty = __popcll(__ballot(!have));
+        const uint32_t n_busy = 64u - n_fin - n_empty;
+        // Lanes that could be put to work now, against the lanes this wave can still use: serve them once they are
+        // a quarter of the wave, or when nothing else is left to do.
+        const uint32_t idle = n_fin + (exhausted ? 0u : n_empty);
+        const uint32_t usable = 64u - (exhausted ? n_empty : 0u);
+        if (n_busy == 0u || idle * 4u >= usable) {
+            if (n_fin && finished) {
+                V3 l;
+                g.o = walk.o;
+                g.d = walk.d;
+                const int outcome = shade_segment<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, g, s_local, pixel, walk.best, l);
+                if (outcome == kPathAlive) {
+                    walk.begin(root_lo, root_hi, sc.root_ref, g.o, g.d, P.z_near, P.z_far);
+                    ++n_rays;
+                } else {
+                    st.radiance[slot] = mk4(l, 0.0f);
+                    have = false;
+                    if (outcome == kPathEndedByEarlyMiss) ++n_rays;
+                }
+            }
+            const unsigned long long empty_mask = __ballot(!have);
+            if (!exhausted && empty_mask) {
+                const uint32_t want = __popcll(empty_mask);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_next, want);
+                base = __shfl(base, 0);
+                if (base + want >= my_items) exhausted = true;
+                if (!have) {
+                    const uint32_t item = base + __popcll(empty_mask & ((1ull << lane) - 1ull));
+                    if (from_queue) {
+                        if (item < my_items) {
+                            slot = queue[seg + item];
+                            const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+                            g.o = xyz(o4);
+                            g.d = xyz(d4);
+                            g.beta = xyz(st.beta[slot]);
+                            g.k = f2u(o4.w) & kDrawMask;
+                            g.flags = f2u(o4.w) >> kDrawBits;
+                            g.depth = f2u(d4.w) & 0xFFFFu;
+                            s_local = f2u(d4.w) >> 16;
+                            pixel = slot - s_local * P.npix;
+                            walk.begin(root_lo, root_hi, sc.root_ref, g.o, g.d, P.z_near, P.z_far);
+                            ++n_rays;
+                            have = true;
+                        }
+                    } else {
+                        slot = ((item / kBlock) * gridDim.x + blockIdx.x) * kBlock + (item % kBlock);
+                        if (item < my_items && slot < n_slots) {
+                            g.k = generate_ray(P, slot, g.o, g.d, s_local, pixel);
+                            g.beta = V3{1.0f, 1.0f, 1.0f};
+                            g.flags = 0u;
+                            g.depth = 0u;
+                            walk.begin(root_lo, root_hi, sc.root_ref, g.o, g.d, P.z_near, P.z_far);
+                            have = true;
+                        }
+                    }
+                }
+            }
+            if (__ballot(have) == 0ull) {
+                if (exhausted) break;
+                continue;
+            }
+        }
+        if (have && walk.cur != kRefNone) walk.step(wide, prims);
+    }
+    for (int sh = 32; sh > 0; sh >>= 1) n_rays += __shfl_down(n_rays, sh);
+    if (lane == 0u && n_rays) atomicAdd(&s_rays, n_rays);
+    __syncthreads();
+    if (threadIdx.x == 0) ray_counts[blockIdx.x] = s_rays;
+}
+
 // Per-bounce ray totals of a batch: totals[it] = sum over blocks of counts[it][b] + early[it][b] (queued rays
 // plus rays whose miss was settled a bounce early).
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ counts,
@@ -1259,6 +1454,24 @@ void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
     if (lds_bytes > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early, spill);
+}
+
+void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
+                        uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *ray_counts, bool need_uv, bool has_mix, int waves,
+                        const StackSpill &spill, bool camera_rays_in_lockstep) {
+    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, StackSpill, uint32_t);
+    constexpr int K = kStackEntriesInLds;
+    Kernel kernel;
+    if (has_mix)
+        kernel = k_paths_lanes<true, true, 4, K>;
+    else if (waves >= 8)
+        kernel = need_uv ? k_paths_lanes<true, false, 8, K> : k_paths_lanes<false, false, 8, K>;
+    else if (waves >= 6)
+        kernel = need_uv ? k_paths_lanes<true, false, 6, K> : k_paths_lanes<false, false, 6, K>;
+    else
+        kernel = need_uv ? k_paths_lanes<true, false, 4, K> : k_paths_lanes<false, false, 4, K>;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), (uint32_t)(K * kBlock * sizeof(uint2)), s, sc, P, st, n_slots, cap, queue,
+                       ray_counts, spill, camera_rays_in_lockstep ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -256,7 +256,7 @@ LDS_PIPELINES = (F.RT_PIPELINE_FUSED_LDS, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELIN
 
 @pytest.mark.parametrize("pipeline", [F.RT_PIPELINE_SPLIT, F.RT_PIPELINE_FUSED, F.RT_PIPELINE_FUSED_LDS,
                                       F.RT_PIPELINE_HYBRID, F.RT_PIPELINE_HYBRID_LDS, F.RT_PIPELINE_SPLIT_LDS,
-                                      F.RT_PIPELINE_PATHS, F.RT_PIPELINE_PATHS_LDS])
+                                      F.RT_PIPELINE_PATHS, F.RT_PIPELINE_PATHS_LDS, F.RT_PIPELINE_LANES])
 def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
     """Split kernels (generate / extend / shade), the fused per-bounce kernel, the hybrid of the two and the
     one-launch-per-batch kernel, each with the scene tables in HBM or staged in LDS, must all give the oracle's
