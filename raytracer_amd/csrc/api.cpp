@@ -95,7 +95,7 @@ struct rt_context {
     uint32_t timed_bounces = 0xFFFFFFFFu;
     uint32_t pipeline = RT_PIPELINE_AUTO;
     bool lanes_lockstep_first = true; // LANES: camera rays in lockstep first (environment variable RT_LANES_FIRST=lanes turns it off)
-    int lanes_waves = 4;              // waves per SIMD of the LANES kernel (environment variable RT_LANES_WAVES)
+    int lanes_waves = 5;              // waves per SIMD of the LANES kernel (environment variable RT_LANES_WAVES)
     int traversal = 0;                // -1 walk, +1 stack, 0 = chosen per scene (environment variable RT_TRAVERSAL)
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
@@ -264,7 +264,7 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
     if (const char *e = std::getenv("RT_LANES_FIRST")) c->lanes_lockstep_first = std::strcmp(e, "lanes") != 0;
     if (const char *e = std::getenv("RT_LANES_WAVES")) {
         long v = std::strtol(e, nullptr, 10);
-        if (v == 4 || v == 6 || v == 8) c->lanes_waves = (int)v;
+        if (v >= 4 && v <= 8 && v != 7) c->lanes_waves = (int)v;
     }
     c->cus = (uint32_t)std::max(1, prop.multiProcessorCount);
     c->max_blocks = c->cus * 8u;
@@ -709,7 +709,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // of that latency than six; 10 M soup 0.286 -> 0.325 Grays/s, while the L2-resident teapot loses 2 % with them.
     const bool eight_waves = pipeline == RT_PIPELINE_PATHS && table_bytes > (16u << 20);
     const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu
-                                   : lanes         ? (uint32_t)(s->has_mix ? 4 : c->lanes_waves) // one resident round
+                                   : lanes         ? (uint32_t)(s->has_mix ? 4 : std::max(6, c->lanes_waves)) // one resident round
                                    : big_blocks    ? 1u
                                    : eight_waves   ? 8u
                                                    : (table_bytes <= 256u * 1024u ? 24u : 6u);
@@ -776,7 +776,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             if (lanes)
-                rt::launch_paths_lanes(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->counts.ptr + grid, s->need_uv,
+                rt::launch_paths_lanes(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->counts.ptr, c->early.ptr, s->need_uv,
                                        s->has_mix, c->lanes_waves, spill, c->lanes_lockstep_first);
             else
                 rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr,

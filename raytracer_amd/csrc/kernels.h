@@ -45,12 +45,13 @@ constexpr int kStackEntriesInLds = 8;
 // One lane per path (k_paths_lanes): the whole batch in one launch without queues or path state in device
 // memory, for scenes read from HBM; needs sc.wide.  `ray_counts[b]` receives the rays block b traced beyond each
 // path's first.  `waves`: waves per SIMD the register budget is set for (4, 6 or 8).
-// `camera_rays_in_lockstep`: trace bounce 0 with 64 neighbouring pixels per wave first (survivors pass through
-// `queue`, one segment of `cap` entries per block, and the ray_o / ray_d / beta arrays of `st`), then one lane per
-// surviving path; otherwise lanes take paths from the camera ray on and `queue` and those arrays are not touched.
+// `camera_rays_in_lockstep`: bounce 0 is traced by the per-bounce kernel first, 64 neighbouring pixels per wave
+// (survivors pass through `queue`, one segment of `cap` entries per block, and the ray_o / ray_d / beta arrays of
+// `st`), then one lane per surviving path; otherwise lanes take paths from the camera ray on and `queue` and those
+// arrays are not touched.  `counts` / `early` are the [max_depth + 1][grid] tables, rows 1.. zeroed by the caller.
 void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                        uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *ray_counts, bool need_uv, bool has_mix, int waves,
-                        const StackSpill &spill, bool camera_rays_in_lockstep);
+                        uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *counts, uint32_t *early, bool need_uv, bool has_mix,
+                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep);
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals);
 

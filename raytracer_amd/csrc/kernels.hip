@@ -963,10 +963,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
 // first copied into LDS and traversal reads them there.
 // ------------------------------------------------------------------------------------------------------
 // Six waves per SIMD: the kernel needs 81 VGPRs unconstrained, one over the 80 that let a sixth wave in.
-template <bool FIRST, bool LDS_SCENE, bool NEED_UV>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
+// STACK: 0 = the stackless walk over the 32-byte node table; K > 0 = the stack traversal over the 64-byte records
+// with K stack entries per lane in LDS (tables in device memory only).
+template <bool FIRST, bool LDS_SCENE, bool NEED_UV, bool HAS_MIX = false, int STACK = 0>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : 6))) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
                                                    uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out,
-                                                   uint32_t *__restrict__ early_out) {
+                                                   uint32_t *__restrict__ early_out, StackSpill spill) {
+    static_assert(!(LDS_SCENE && STACK), "the stack traversal reads its tables from device memory");
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_out, s_early;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
@@ -1005,9 +1008,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
                 s_local = f2u(d4.w) >> 16;
                 pixel = slot - s_local * P.npix;
             }
-            uint32_t c0 = 0, c1 = 0, c2 = 0;
-            Closest best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-            alive = shade_path<NEED_UV, false>(sc, root_lo, root_hi, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
+            Closest best;
+            if constexpr (STACK != 0) {
+                best = traverse_stack<(STACK ? STACK : 1), kBlock>(reinterpret_cast<const float4 *>(sc.wide), prims, root_lo, root_hi, sc.root_ref,
+                                                                  o, d, P.z_near, P.z_far, reinterpret_cast<uint2 *>(s_scene), spill);
+            } else {
+                uint32_t c0 = 0, c1 = 0, c2 = 0;
+                best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+            }
+            alive = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
         }
         compact_survivors(alive, slot, lane, &s_out, &s_early, queue_out, c.seg);
     }
@@ -1139,63 +1148,38 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
 // in sample order by k_accumulate, so the sums do not depend on which lane traced what.
 // `ray_counts[b]`: rays beyond the first of each path that block b traced (settled early misses included).
 // ------------------------------------------------------------------------------------------------------
-template <bool NEED_UV, bool HAS_MIX, int WAVES, int K>
+// FROM_CAMERA: lanes take paths from the camera ray on (the block's round-robin share of the batch).  Otherwise
+// bounce 0 has been traced by k_bounce (64 neighbouring pixels per wave in lockstep: their walks touch the same
+// nodes, which the vector cache then fetches once per wave) and lanes take the surviving paths from the block's
+// segment of `queue` (`pool[b]` entries), whose first rays the caller has counted already.
+template <bool NEED_UV, bool HAS_MIX, int WAVES, int K, bool FROM_CAMERA>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : WAVES))) void k_paths_lanes(
-    SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue,
-    uint32_t *__restrict__ ray_counts, StackSpill spill, uint32_t camera_rays_in_lockstep) {
+    SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, const uint32_t *__restrict__ queue,
+    const uint32_t *__restrict__ pool, uint32_t *__restrict__ ray_counts, StackSpill spill) {
     extern __shared__ float4 s_scene[];
-    __shared__ uint32_t s_next, s_rays, s_out, s_early;
+    __shared__ uint32_t s_next, s_rays;
     const float4 *__restrict__ wide = reinterpret_cast<const float4 *>(sc.wide);
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
     if (threadIdx.x == 0) {
         s_next = 0u;
         s_rays = 0u;
-        s_out = 0u;
-        s_early = 0u;
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t seg = blockIdx.x * cap;
-    // the block's share of the batch: its round-robin 256-slot chunks
-    const uint32_t chunks = (n_slots + kBlock - 1) / kBlock;
-    uint32_t my_items = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
+    uint32_t my_items;
+    if (FROM_CAMERA) {
+        const uint32_t chunks = (n_slots + kBlock - 1) / kBlock;
+        my_items = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
+    } else {
+        my_items = pool[blockIdx.x];
+    }
 
     StackWalk<K, kBlock> walk;
     walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
     Segment g{};
     uint32_t slot = 0, s_local = 0, pixel = 0, n_rays = 0;
-
-    // Camera rays first, 64 neighbouring pixels per wave in lockstep: their walks touch the same nodes, which the
-    // vector cache then fetches once per wave.  Survivors go to the block's queue segment with their state.
-    const bool from_queue = camera_rays_in_lockstep != 0u;
-    if (from_queue) {
-        const uint32_t my_quarters = my_items / 64u;
-        for (;;) {
-            uint32_t quarter = 0;
-            if (lane == 0) quarter = atomicAdd(&s_next, 1u);
-            quarter = __shfl(quarter, 0);
-            if (quarter >= my_quarters) break;
-            slot = ((quarter >> 2) * gridDim.x + blockIdx.x) * kBlock + (quarter & 3u) * 64u + lane;
-            int outcome = kPathEnded;
-            if (slot < n_slots) {
-                V3 o, d;
-                const uint32_t k = generate_ray(P, slot, o, d, s_local, pixel);
-                walk.begin(root_lo, root_hi, sc.root_ref, o, d, P.z_near, P.z_far);
-                while (walk.cur != kRefNone) walk.step(wide, prims);
-                outcome = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, V3{1.0f, 1.0f, 1.0f}, k, 0u, 0u,
-                                                       s_local, pixel, walk.best);
-            }
-            compact_survivors(outcome, slot, lane, &s_out, &s_early, queue, seg);
-        }
-        __syncthreads(); // the appends and the state behind them are complete and visible
-        my_items = s_out;
-        if (threadIdx.x == 0) {
-            s_next = 0u;
-            s_rays = s_early;
-        }
-        __syncthreads();
-    }
 
     bool have = false, exhausted = false;
     walk.cur = kRefNone;
@@ -1232,7 +1216,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                 if (base + want >= my_items) exhausted = true;
                 if (!have) {
                     const uint32_t item = base + __popcll(empty_mask & ((1ull << lane) - 1ull));
-                    if (from_queue) {
+                    if (!FROM_CAMERA) {
                         if (item < my_items) {
                             slot = queue[seg + item];
                             const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
@@ -1245,7 +1229,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                             s_local = f2u(d4.w) >> 16;
                             pixel = slot - s_local * P.npix;
                             walk.begin(root_lo, root_hi, sc.root_ref, g.o, g.d, P.z_near, P.z_far);
-                            ++n_rays;
                             have = true;
                         }
                     } else {
@@ -1400,14 +1383,14 @@ static void launch_bounce_t(hipStream_t s, uint32_t grid, const SceneDev &sc, co
     dim3 g(grid), b(kBlock);
     if (lds_bytes) {
         if (need_uv)
-            hipLaunchKernelGGL((k_bounce<FIRST, true, true>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, true, true>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
         else
-            hipLaunchKernelGGL((k_bounce<FIRST, true, false>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, true, false>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
     } else {
         if (need_uv)
-            hipLaunchKernelGGL((k_bounce<FIRST, false, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, false, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
         else
-            hipLaunchKernelGGL((k_bounce<FIRST, false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out);
+            hipLaunchKernelGGL((k_bounce<FIRST, false, false>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
     }
 }
 
@@ -1457,21 +1440,32 @@ void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
 }
 
 void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
-                        uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *ray_counts, bool need_uv, bool has_mix, int waves,
-                        const StackSpill &spill, bool camera_rays_in_lockstep) {
-    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, StackSpill, uint32_t);
+                        uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *counts, uint32_t *early, bool need_uv, bool has_mix,
+                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep) {
     constexpr int K = kStackEntriesInLds;
+    const uint32_t stack_bytes = (uint32_t)(K * kBlock * sizeof(uint2));
+    if (camera_rays_in_lockstep) { // bounce 0 by the per-bounce kernel: survivors into `queue`, rows 1 of the tables
+        const QueueView all{nullptr, nullptr, cap, n_slots};
+        auto first = has_mix ? k_bounce<true, false, true, true, K> : need_uv ? k_bounce<true, false, true, false, K> : k_bounce<true, false, false, false, K>;
+        hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), stack_bytes, s, sc, P, st, all, queue, counts + grid, early + grid, spill);
+        if (P.max_depth < 2u) return;
+    }
+    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, StackSpill);
     Kernel kernel;
-    if (has_mix)
-        kernel = k_paths_lanes<true, true, 4, K>;
-    else if (waves >= 8)
-        kernel = need_uv ? k_paths_lanes<true, false, 8, K> : k_paths_lanes<false, false, 8, K>;
-    else if (waves >= 6)
-        kernel = need_uv ? k_paths_lanes<true, false, 6, K> : k_paths_lanes<false, false, 6, K>;
+#define RT_LANES_KERNEL(FROM_CAMERA)                                                                                             \
+    (has_mix      ? k_paths_lanes<true, true, 4, K, FROM_CAMERA>                                                                   \
+     : waves >= 8 ? (need_uv ? k_paths_lanes<true, false, 8, K, FROM_CAMERA> : k_paths_lanes<false, false, 8, K, FROM_CAMERA>)     \
+     : waves >= 6 ? (need_uv ? k_paths_lanes<true, false, 6, K, FROM_CAMERA> : k_paths_lanes<false, false, 6, K, FROM_CAMERA>)     \
+     : waves >= 5 ? (need_uv ? k_paths_lanes<true, false, 5, K, FROM_CAMERA> : k_paths_lanes<false, false, 5, K, FROM_CAMERA>)     \
+                  : (need_uv ? k_paths_lanes<true, false, 4, K, FROM_CAMERA> : k_paths_lanes<false, false, 4, K, FROM_CAMERA>))
+    if (camera_rays_in_lockstep)
+        kernel = RT_LANES_KERNEL(false);
     else
-        kernel = need_uv ? k_paths_lanes<true, false, 4, K> : k_paths_lanes<false, false, 4, K>;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), (uint32_t)(K * kBlock * sizeof(uint2)), s, sc, P, st, n_slots, cap, queue,
-                       ray_counts, spill, camera_rays_in_lockstep ? 1u : 0u);
+        kernel = RT_LANES_KERNEL(true);
+#undef RT_LANES_KERNEL
+    // rays beyond those the tables already hold: bounce 0's survivors are row 1, so the lanes' own count is row 2
+    uint32_t *ray_counts = counts + (size_t)(camera_rays_in_lockstep ? 2u : 1u) * grid;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), stack_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid, ray_counts, spill);
 }
 
 // ------------------------------------------------------------------------------------------------------
