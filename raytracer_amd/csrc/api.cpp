@@ -94,9 +94,8 @@ struct rt_context {
     uint64_t max_paths = 1ull << 26;
     uint32_t timed_bounces = 0xFFFFFFFFu;
     uint32_t pipeline = RT_PIPELINE_AUTO;
-    bool lanes_lockstep_first = true; // LANES: camera rays in lockstep first (environment variable RT_LANES_FIRST=lanes turns it off)
-    int lanes_waves = 5;              // waves per SIMD of the LANES kernel (environment variable RT_LANES_WAVES)
-    int traversal = 0;                // -1 walk, +1 stack, 0 = chosen per scene (environment variable RT_TRAVERSAL)
+    bool lanes_lockstep_first = false; // LANES: camera rays by the per-bounce kernel first (environment variable RT_LANES_FIRST=lockstep)
+    int lanes_waves = 4;              // waves per SIMD the LANES kernel's registers are budgeted for (RT_LANES_WAVES)              // waves per SIMD of the LANES kernel (environment variable RT_LANES_WAVES)
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
     // wavefront workspace
@@ -220,7 +219,7 @@ template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **ds
     *dst = nullptr;
     size_t n = v.size() ? v.size() : 1;
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, n * sizeof(T) + 64)); // slack: the stack traversal reads 64 bytes at a 48-byte record
+    HIP_TRY(hipMalloc(&p, n * sizeof(T) + 128)); // slack: the stack traversal reads 128 bytes at a 48-byte record
     s->blocks[s->n_blocks++] = p;
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T *>(p);
@@ -259,9 +258,7 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
         long v = std::strtol(e, nullptr, 10);
         if (v >= 1 && v <= 64) c->blocks_per_cu = (uint32_t)v;
     }
-    if (const char *e = std::getenv("RT_TRAVERSAL")) // tuning knob for experiments: "walk" or "stack"
-        c->traversal = !std::strcmp(e, "walk") ? -1 : !std::strcmp(e, "stack") ? 1 : 0;
-    if (const char *e = std::getenv("RT_LANES_FIRST")) c->lanes_lockstep_first = std::strcmp(e, "lanes") != 0;
+    if (const char *e = std::getenv("RT_LANES_FIRST")) c->lanes_lockstep_first = std::strcmp(e, "lockstep") == 0;
     if (const char *e = std::getenv("RT_LANES_WAVES")) {
         long v = std::strtol(e, nullptr, 10);
         if (v >= 4 && v <= 8 && v != 7) c->lanes_waves = (int)v;
@@ -414,20 +411,20 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
     }
     s->dev.n_nodes = d_nodes ? (uint32_t)n_nodes_device : (uint32_t)hs.nodes.size();
     s->dev.n_prims = (uint32_t)hs.prims.size();
-    // The 64-byte records of the stack traversal, derived on the device from the node table just uploaded.
+    // The 128-byte records of the stack traversal, derived on the device from the node table just uploaded.
     s->dev.depth = hs.depth;
     s->dev.root_ref = root.leaf == rt::kInterior ? 0u
                                                  : (rt::kRefLeaf | ((root.leaf & rt::kSphereBit) ? rt::kRefSphere : 0u) | (root.leaf & ~rt::kSphereBit));
     if (s->dev.n_prims <= rt::kRefIndex) {
         void *p = nullptr;
-        const size_t wide_bytes = (size_t)std::max<uint32_t>(1u, s->dev.n_prims - 1u) * sizeof(rt::WideNode);
+        const size_t wide_bytes = (size_t)std::max<uint32_t>(1u, s->dev.n_prims - 1u) * sizeof(rt::ChainNode);
         if (hipMalloc(&p, wide_bytes) != hipSuccess) {
             rt_scene_destroy(s);
             return set_error(RT_ERR_OUT_OF_MEMORY, "out of device memory for the BVH node records");
         }
         s->blocks[s->n_blocks++] = p;
-        s->dev.wide = static_cast<const rt::WideNode *>(p);
-        rt::build_wide_nodes(c->stream, s->dev.nodes, s->dev.n_nodes, static_cast<rt::WideNode *>(p));
+        s->dev.chain = static_cast<const rt::ChainNode *>(p);
+        rt::build_chain_nodes(c->stream, s->dev.nodes, s->dev.n_nodes, static_cast<rt::ChainNode *>(p));
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
             rt_scene_destroy(s);
             return set_error(RT_ERR_DEVICE, "building the BVH node records failed");
@@ -674,14 +671,20 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     uint32_t pipeline = c->pipeline;
     // AUTO: tables up to 40 KB go to LDS once per 256-thread block; up to 150 KB once per 1024-thread block, one
     // block per CU (485 spheres, 54 KB: 12.4 vs 8.8 Grays/s from L1/L2); larger scenes are read through the caches.
-    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_PATHS;
+    // Tables far beyond what the L2s hold (32 MiB in all) are read from HBM, where the number of cache lines fetched
+    // per ray is what counts: one lane per path over the 128-byte records (10 M triangles 0.44 vs 0.37 Grays/s, 1 M
+    // 0.81 vs 0.74; a cache-resident 100 k soup 2.3 vs 3.8, the teapot 3.7 vs 4.9: those stay with PATHS).
+    if (pipeline == RT_PIPELINE_AUTO)
+        pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS
+                   : (table_bytes > (64u << 20) && s->dev.chain) ? RT_PIPELINE_LANES
+                                                                 : RT_PIPELINE_PATHS;
     bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
                pipeline == RT_PIPELINE_PATHS_LDS;
     if (count) {
         if (c->pipeline == RT_PIPELINE_AUTO && table_bytes > 64u * 1024u) lds = false;
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     }
-    if (pipeline == RT_PIPELINE_LANES && !s->dev.wide) pipeline = RT_PIPELINE_PATHS;
+    if (pipeline == RT_PIPELINE_LANES && !s->dev.chain) pipeline = RT_PIPELINE_PATHS;
     const bool lanes = pipeline == RT_PIPELINE_LANES;
     if (s->has_mix && pipeline != RT_PIPELINE_PATHS && pipeline != RT_PIPELINE_PATHS_LDS && !lanes)
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
@@ -694,11 +697,8 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
     // Traversal of the PATHS kernels: the stack traversal over 64-byte records, or the stackless walk over the
     // 32-byte node table.
-    const uint64_t wide_table_bytes = (uint64_t)(s->dev.n_prims - 1u) * sizeof(rt::WideNode) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim) + 16u;
-    const uint64_t stack_lds_bytes = (uint64_t)rt::kStackEntriesInLds * (big_blocks ? 1024u : 256u) * sizeof(uint2);
-    const bool stack = lanes || (paths && s->dev.wide && (c->traversal > 0 || (c->traversal == 0 && !lds)) &&
-                       (!lds || wide_table_bytes + stack_lds_bytes <= 159u * 1024u));
-    const uint32_t lds_bytes = lds ? (uint32_t)(stack ? wide_table_bytes : table_bytes) : 0u;
+    const bool stack = lanes;
+    const uint32_t lds_bytes = lds ? (uint32_t)table_bytes : 0u;
     // One grid for every bounce of a batch: block b owns segment b of both queues (see QueueView).
     const uint32_t chunks = (uint32_t)((slots + 255) / 256);
     // A CU holds six of these 256-thread blocks (six waves per SIMD) and whole rounds of six run best.  Scenes
@@ -709,7 +709,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // of that latency than six; 10 M soup 0.286 -> 0.325 Grays/s, while the L2-resident teapot loses 2 % with them.
     const bool eight_waves = pipeline == RT_PIPELINE_PATHS && table_bytes > (16u << 20);
     const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu
-                                   : lanes         ? (uint32_t)(s->has_mix ? 4 : std::max(6, c->lanes_waves)) // one resident round
+                                   : lanes         ? 4u // one resident round; more walks in flight thrash the L2s
                                    : big_blocks    ? 1u
                                    : eight_waves   ? 8u
                                                    : (table_bytes <= 256u * 1024u ? 24u : 6u);
@@ -780,7 +780,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
                                        s->has_mix, c->lanes_waves, spill, c->lanes_lockstep_first);
             else
                 rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr,
-                                 c->early.ptr, s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves, stack, spill);
+                                 c->early.ptr, s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves);
             if (int rc = timed_end(c)) return rc;
             ++bounce_launches;
         }

@@ -18,8 +18,8 @@ namespace rt {
 int build_bvh_device(hipStream_t stream, const BuildBox *h_boxes, uint32_t n, uint32_t sphere_begin, uint32_t sphere_end,
                      Node *d_nodes, uint32_t *h_order, uint32_t *depth, std::string &err);
 
-// Fills the table of 64-byte records (WideNode, rt_device.h) from the pre-order node table `d_nodes` of
-// `n_nodes` = 2 * primitives - 1 entries; `d_wide` holds primitives - 1 records.  Asynchronous on `stream`.
-void build_wide_nodes(hipStream_t stream, const Node *d_nodes, uint32_t n_nodes, WideNode *d_wide);
+// Fills the table of 128-byte records (ChainNode, rt_device.h) from the pre-order node table `d_nodes` of
+// `n_nodes` = 2 * primitives - 1 entries; `d_chain` holds primitives - 1 records.  Asynchronous on `stream`.
+void build_chain_nodes(hipStream_t stream, const Node *d_nodes, uint32_t n_nodes, ChainNode *d_chain);
 
 } // namespace rt

@@ -259,26 +259,79 @@ __device__ __forceinline__ uint32_t child_ref(const Node *__restrict__ nodes, ui
     return kRefLeaf | ((leaf & kSphereBit) ? kRefSphere : 0u) | (leaf & ~kSphereBit);
 }
 
-__global__ __launch_bounds__(kThreads) void k_wide(const Node *__restrict__ nodes, uint32_t n_nodes, WideNode *__restrict__ wide) {
+// The six planes of a node's box in the order xlo, xhi, ylo, yhi, zlo, zhi.
+__device__ __forceinline__ void planes_of(const Node &n, float p[6]) {
+    p[0] = n.xlo, p[1] = n.xhi, p[2] = n.ylo, p[3] = n.yhi, p[4] = n.zlo, p[5] = n.zhi;
+}
+
+// Children `a` (left) and `b` (right) of a node with planes `parent`: true when every plane of the parent is, bit
+// for bit, the plane of at least one child; then `fresh[k]` is the other child's plane and bit k of `mask` says
+// that the left child is the one that inherits.
+__device__ __forceinline__ bool encode_pair(const float parent[6], const Node &a, const Node &b, float fresh[6], uint32_t &mask) {
+    float pa[6], pb[6];
+    planes_of(a, pa);
+    planes_of(b, pb);
+    mask = 0u;
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t want = __float_as_uint(parent[k]);
+        if (__float_as_uint(pa[k]) == want) {
+            mask |= 1u << k;
+            fresh[k] = pb[k];
+        } else if (__float_as_uint(pb[k]) == want) {
+            fresh[k] = pa[k];
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kThreads) void k_chain(const Node *__restrict__ nodes, uint32_t n_nodes, ChainNode *__restrict__ chain) {
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_nodes; i += gridDim.x * kThreads) {
         if (nodes[i].leaf != kInterior) continue;
         const uint32_t l = i + 1, r = nodes[l].skip;
         const Node a = nodes[l], b = nodes[r];
-        WideNode w;
+        ChainNode w{};
         w.lx[0] = a.xlo, w.lx[1] = a.xhi, w.ly[0] = a.ylo, w.ly[1] = a.yhi, w.lz[0] = a.zlo, w.lz[1] = a.zhi;
         w.rx[0] = b.xlo, w.rx[1] = b.xhi, w.ry[0] = b.ylo, w.ry[1] = b.yhi, w.rz[0] = b.zlo, w.rz[1] = b.zhi;
         w.left = child_ref(nodes, l);
         w.right = child_ref(nodes, r);
-        w.pad[0] = w.pad[1] = 0u;
-        wide[i - leaves_before(nodes, i)] = w;
+        uint32_t levels = 1u, mask1 = 0u, mask2 = 0u;
+        if (a.leaf == kInterior) { // the children of L, told from L's box
+            const uint32_t ll = l + 1, lr = nodes[ll].skip;
+            const Node c = nodes[ll], d = nodes[lr];
+            float parent[6], fresh[6];
+            planes_of(a, parent);
+            if (encode_pair(parent, c, d, fresh, mask1)) {
+                levels = 2u;
+                w.n1xy[0] = fresh[0], w.n1xy[1] = fresh[1], w.n1xy[2] = fresh[2], w.n1xy[3] = fresh[3];
+                w.n1z[0] = fresh[4], w.n1z[1] = fresh[5];
+                w.ll = child_ref(nodes, ll);
+                w.lr = child_ref(nodes, lr);
+                if (c.leaf == kInterior) { // the children of LL, told from LL's box
+                    const uint32_t lll = ll + 1, llr = nodes[lll].skip;
+                    const Node e = nodes[lll], f = nodes[llr];
+                    planes_of(c, parent);
+                    if (encode_pair(parent, e, f, fresh, mask2)) {
+                        levels = 3u;
+                        w.n2xy[0] = fresh[0], w.n2xy[1] = fresh[1], w.n2xy[2] = fresh[2], w.n2xy[3] = fresh[3];
+                        w.n2z[0] = fresh[4], w.n2z[1] = fresh[5];
+                        w.lll = child_ref(nodes, lll);
+                        w.llr = child_ref(nodes, llr);
+                    }
+                }
+            }
+        }
+        w.meta = mask1 | (mask2 << 8) | (levels << 16);
+        chain[i - leaves_before(nodes, i)] = w;
     }
 }
 
 } // namespace
 
-void build_wide_nodes(hipStream_t stream, const Node *d_nodes, uint32_t n_nodes, WideNode *d_wide) {
+void build_chain_nodes(hipStream_t stream, const Node *d_nodes, uint32_t n_nodes, ChainNode *d_chain) {
     const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_nodes + kThreads - 1) / kThreads, 1u << 16);
-    hipLaunchKernelGGL(k_wide, dim3(grid), dim3(kThreads), 0, stream, d_nodes, n_nodes, d_wide);
+    hipLaunchKernelGGL(k_chain, dim3(grid), dim3(kThreads), 0, stream, d_nodes, n_nodes, d_chain);
 }
 
 int build_bvh_device(hipStream_t stream, const BuildBox *h_boxes, uint32_t n, uint32_t sphere_begin, uint32_t sphere_end,

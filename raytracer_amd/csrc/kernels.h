@@ -37,13 +37,11 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 // All bounces of a batch in one launch (k_paths); `counts` / `early` rows 1 .. max_depth must be zero.
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves, bool stack, const StackSpill &spill);
-// `stack`: traverse the 64-byte node records with a per-lane stack (sc.wide must be set; `lds_bytes`, when not
-// zero, then counts those records + the primitives + 16 bytes).  The stack keeps kStackEntriesInLds entries per
-// lane in LDS (added to the launch's LDS size here) and the rest in `spill`.
+                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves);
+// Entries per lane of the stack traversal's stack that live in LDS; deeper ones go to the spill area.
 constexpr int kStackEntriesInLds = 8;
 // One lane per path (k_paths_lanes): the whole batch in one launch without queues or path state in device
-// memory, for scenes read from HBM; needs sc.wide.  `ray_counts[b]` receives the rays block b traced beyond each
+// memory, for scenes read from HBM; needs sc.chain.  `ray_counts[b]` receives the rays block b traced beyond each
 // path's first.  `waves`: waves per SIMD the register budget is set for (4, 6 or 8).
 // `camera_rays_in_lockstep`: bounce 0 is traced by the per-bounce kernel first, 64 neighbouring pixels per wave
 // (survivors pass through `queue`, one segment of `cap` entries per block, and the ray_o / ray_d / beta arrays of

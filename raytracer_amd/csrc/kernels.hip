@@ -187,7 +187,7 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
 }
 
 // ------------------------------------------------------------------------------------------------------
-// BvhNode::hit with the child boxes stored in the parent (WideNode, rt_device.h) and a per-lane stack.
+// BvhNode::hit with the child boxes stored in the parent (ChainNode, rt_device.h) and a per-lane stack.
 //
 // Aabb::hit narrows [lo, hi] = [t_min, closest so far] by the three slabs and reports a hit unless hi <= lo.
 // The slabs' contribution does not depend on the closest distance: with E = max(t_min, the three entry
@@ -199,7 +199,12 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
 // closest distance only shrinks, a right child that fails at push time would fail later too, and one that passed
 // (so X > E) passes later iff closest > E: the stack entry needs E only.  Visiting order, primitive tests and
 // every comparison are the reference's; what changes is that a node whose box is missed costs no memory access
-// and an entered node costs one 64-byte read.
+// and one 128-byte read serves up to three nodes of a left descent.
+//
+// Why 128-byte records: a scattered read costs the memory system one 128-byte line whatever part of it is used
+// (measured: 5.4e10 reads/s of 32 bytes, 5.3e10 of 64, 5.0e10 of 128, 2.3e10 of 256 from a 2 GB table), and with a
+// few thousand independent walks per L2 only the top ten levels of a large tree stay cached, so the number of
+// lines fetched per ray is what bounds a scene read from HBM.
 //
 // The stack: the K most recent entries live in LDS (entry e of a thread at lds[(e % K) * THREADS]), older ones
 // are moved to `spill` in device memory and come back when the LDS part runs empty.  At most depth - 1 entries
@@ -274,12 +279,30 @@ struct StackWalk {
         slab_pair(root_lo.x, root_lo.y, root_lo.z, root_lo.w, root_hi.x, root_hi.y, o, inv, tmin, E, X);
         cur = !(min_raw(best.t, X) <= E) ? root_ref : kRefNone;
     }
-    __device__ __forceinline__ void step(const float4 *__restrict__ wide, const float4 *__restrict__ prims) {
+    // One pair of children of a node with planes `parent` (xlo, xhi, ylo, yhi, zlo, zhi): plane k of the left
+    // child is the parent's when bit k of `mask` is set and `fresh[k]` otherwise, the right child takes the other.
+    // Decides both boxes; the left child's planes are left in `parent` for the next level.
+    __device__ __forceinline__ void pair_below(float parent[6], const float fresh[6], uint32_t mask, bool &hit_l, bool &hit_r, float &er) {
+        float right[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool inherit = (mask >> k) & 1u;
+            right[k] = inherit ? fresh[k] : parent[k];
+            parent[k] = inherit ? parent[k] : fresh[k];
+        }
+        float el, xl, xr;
+        slab_pair(parent[0], parent[1], parent[2], parent[3], parent[4], parent[5], o, inv, tmin, el, xl);
+        slab_pair(right[0], right[1], right[2], right[3], right[4], right[5], o, inv, tmin, er, xr);
+        hit_l = !(min_raw(best.t, xl) <= el);
+        hit_r = !(min_raw(best.t, xr) <= er);
+    }
+
+    __device__ __forceinline__ void step(const float4 *__restrict__ chain, const float4 *__restrict__ prims) {
         const bool leaf = (cur & kRefLeaf) != 0u;
         const uint32_t index = cur & kRefIndex;
-        // one memory round per step whatever the lanes hold: 64 bytes of a node record, or the 48 bytes of a
-        // primitive (the fourth quad is then the head of the next record; the tables are padded for it)
-        const float4 *__restrict__ p = leaf ? prims + 3 * (size_t)index : wide + 4 * (size_t)index;
+        // one memory round per step whatever the lanes hold: the 128 bytes of a node record, or the 48 bytes of a
+        // primitive (the other quads are then the records that follow; the table is padded for it)
+        const float4 *__restrict__ p = leaf ? prims + 3 * (size_t)index : chain + 8 * (size_t)index;
         const float4 a = p[0], b = p[1], c = p[2], q = p[3];
         uint32_t next = kRefNone;
         if (leaf) {
@@ -288,16 +311,37 @@ struct StackWalk {
             else
                 tri_test(a, b, c, index, o, d, tmin, best);
         } else {
+            const float4 n1 = p[4], nz = p[5], n2 = p[6], refs = p[7];
+            const uint32_t meta = f2u(q.z);
+            const uint32_t levels = meta >> 16;
             float el, xl, er, xr;
             slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, el, xl);
             slab_pair(c.x, c.y, c.z, c.w, b.z, b.w, o, inv, tmin, er, xr);
-            const bool hit_l = !(min_raw(best.t, xl) <= el);
-            const bool hit_r = !(min_raw(best.t, xr) <= er);
-            if (hit_l) {
+            bool hit_l = !(min_raw(best.t, xl) <= el);
+            bool hit_r = !(min_raw(best.t, xr) <= er);
+            if (hit_r && hit_l) stack.push(er, f2u(q.y));
+            if (!hit_l) {
+                if (hit_r) next = f2u(q.y);
+            } else if (levels < 2u) {
                 next = f2u(q.x);
-                if (hit_r) stack.push(er, f2u(q.y));
-            } else if (hit_r) {
-                next = f2u(q.y);
+            } else { // L's children, from L's box
+                float box[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+                const float fresh1[6] = {n1.x, n1.y, n1.z, n1.w, nz.x, nz.y};
+                pair_below(box, fresh1, meta, hit_l, hit_r, er);
+                if (hit_r && hit_l) stack.push(er, f2u(refs.y));
+                if (!hit_l) {
+                    if (hit_r) next = f2u(refs.y);
+                } else if (levels < 3u) {
+                    next = f2u(refs.x);
+                } else { // LL's children, from LL's box
+                    const float fresh2[6] = {n2.x, n2.y, n2.z, n2.w, nz.z, nz.w};
+                    pair_below(box, fresh2, meta >> 8, hit_l, hit_r, er);
+                    if (hit_r && hit_l) stack.push(er, f2u(refs.w));
+                    if (hit_l)
+                        next = f2u(refs.z);
+                    else if (hit_r)
+                        next = f2u(refs.w);
+                }
             }
         }
         while (next == kRefNone && stack.sp > 0u) {
@@ -309,13 +353,13 @@ struct StackWalk {
 };
 
 template <int K, int THREADS>
-__device__ __forceinline__ Closest traverse_stack(const float4 *__restrict__ wide, const float4 *__restrict__ prims,
+__device__ __forceinline__ Closest traverse_stack(const float4 *__restrict__ chain, const float4 *__restrict__ prims,
                                                   float4 root_lo, float4 root_hi, uint32_t root_ref, V3 o, V3 d, float tmin,
                                                   float tmax, uint2 *lds_stack, StackSpill spill) {
     StackWalk<K, THREADS> walk;
     walk.init(lds_stack, spill);
     walk.begin(root_lo, root_hi, root_ref, o, d, tmin, tmax);
-    while (walk.cur != kRefNone) walk.step(wide, prims);
+    while (walk.cur != kRefNone) walk.step(chain, prims);
     return walk.best;
 }
 
@@ -659,19 +703,6 @@ __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *l
     prims = lds + n4_nodes;
 }
 
-// The same for the stack traversal: node records (WideNode) + primitives, followed by one spare quad (a leaf step
-// reads four quads of a three-quad primitive record).  Returns the first quad after the copy.
-__device__ __forceinline__ float4 *stage_wide_scene_in_lds(const SceneDev &sc, float4 *lds, const float4 *&wide,
-                                                           const float4 *&prims) {
-    const uint32_t n4_wide = 4u * (sc.n_prims - 1u), n4_prims = 3u * sc.n_prims;
-    for (uint32_t i = threadIdx.x; i < n4_wide; i += blockDim.x) lds[i] = wide[i];
-    for (uint32_t i = threadIdx.x; i < n4_prims; i += blockDim.x) lds[n4_wide + i] = prims[i];
-    if (threadIdx.x == 0) lds[n4_wide + n4_prims] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    wide = lds;
-    prims = lds + n4_wide;
-    return lds + n4_wide + n4_prims + 1u;
-}
-
 // ------------------------------------------------------------------------------------------------------
 // extend: closest hit of every queued ray.
 //
@@ -963,7 +994,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
 // first copied into LDS and traversal reads them there.
 // ------------------------------------------------------------------------------------------------------
 // Six waves per SIMD: the kernel needs 81 VGPRs unconstrained, one over the 80 that let a sixth wave in.
-// STACK: 0 = the stackless walk over the 32-byte node table; K > 0 = the stack traversal over the 64-byte records
+// STACK: 0 = the stackless walk over the 32-byte node table; K > 0 = the stack traversal over the 128-byte records
 // with K stack entries per lane in LDS (tables in device memory only).
 template <bool FIRST, bool LDS_SCENE, bool NEED_UV, bool HAS_MIX = false, int STACK = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : 6))) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
@@ -1010,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
             }
             Closest best;
             if constexpr (STACK != 0) {
-                best = traverse_stack<(STACK ? STACK : 1), kBlock>(reinterpret_cast<const float4 *>(sc.wide), prims, root_lo, root_hi, sc.root_ref,
+                best = traverse_stack<(STACK ? STACK : 1), kBlock>(reinterpret_cast<const float4 *>(sc.chain), prims, root_lo, root_hi, sc.root_ref,
                                                                   o, d, P.z_near, P.z_far, reinterpret_cast<uint2 *>(s_scene), spill);
             } else {
                 uint32_t c0 = 0, c1 = 0, c2 = 0;
@@ -1039,32 +1070,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
 // WAVES: waves per SIMD the register budget is set for.  Six fit without spilling and suit scenes served by LDS
 // or the caches; scenes read from HBM gain more from eight waves in flight than the few spilled registers cost.
 // HAS_MIX: the scene holds Mix materials (evaluated by scatter_material instead of scatter_leaf).
-// STACK: 0 = the stackless walk over the 32-byte node table (traverse); K > 0 = the stack traversal over the 64-byte
-// records with K stack entries per lane in LDS (traverse_stack).
-template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false, int STACK = 0>
+template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREADS == kBlock && !HAS_MIX) ? WAVES : 4))) void k_paths(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
-    uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early, StackSpill spill) {
+    uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_out, s_early, s_next;
-    const float4 *nodes = reinterpret_cast<const float4 *>(STACK ? static_cast<const void *>(sc.wide) : static_cast<const void *>(sc.nodes));
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
-    const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
-    uint2 *lds_stack = reinterpret_cast<uint2 *>(s_scene);
-    if (LDS_SCENE) {
-        if (STACK)
-            lds_stack = reinterpret_cast<uint2 *>(stage_wide_scene_in_lds(sc, s_scene, nodes, prims));
-        else
-            stage_scene_in_lds(sc, s_scene, nodes, prims);
-    }
+    const float4 root_lo = nodes[0], root_hi = nodes[1];
+    if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
     auto closest_hit = [&](V3 o, V3 d) {
-        if constexpr (STACK != 0) {
-            return traverse_stack<(STACK ? STACK : 1), THREADS>(nodes, prims, root_lo, root_hi, sc.root_ref, o, d, P.z_near, P.z_far,
-                                                               lds_stack, spill);
-        } else {
-            uint32_t c0 = 0, c1 = 0, c2 = 0;
-            return traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
-        }
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+        return traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
     };
     if (threadIdx.x == 0) {
         s_out = 0u;
@@ -1158,7 +1176,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
     const uint32_t *__restrict__ pool, uint32_t *__restrict__ ray_counts, StackSpill spill) {
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_next, s_rays;
-    const float4 *__restrict__ wide = reinterpret_cast<const float4 *>(sc.wide);
+    const float4 *__restrict__ chain = reinterpret_cast<const float4 *>(sc.chain);
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
     if (threadIdx.x == 0) {
@@ -1249,7 +1267,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                 continue;
             }
         }
-        if (have && walk.cur != kRefNone) walk.step(wide, prims);
+        if (have && walk.cur != kRefNone) walk.step(chain, prims);
     }
     for (int sh = 32; sh > 0; sh >>= 1) n_rays += __shfl_down(n_rays, sh);
     if (lane == 0u && n_rays) atomicAdd(&s_rays, n_rays);
@@ -1405,38 +1423,24 @@ void launch_bounce(hipStream_t s, uint32_t grid, const SceneDev &sc, const Rende
 
 void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st, uint32_t n_slots,
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
-                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves, bool stack, const StackSpill &spill) {
-    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, StackSpill);
+                  bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves) {
+    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *);
     Kernel kernel;
     uint32_t threads = kBlock;
-    constexpr int K = kStackEntriesInLds;
     // Scenes with Mix materials use the instances that also interpolate texture coordinates.
     if (!lds_bytes && eight_waves) {
-        if (stack)
-            kernel = has_mix ? k_paths<false, true, kBlock, 8, true, K> : need_uv ? k_paths<false, true, kBlock, 8, false, K> : k_paths<false, false, kBlock, 8, false, K>;
-        else
-            kernel = has_mix ? k_paths<false, true, kBlock, 8, true> : need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
+        kernel = has_mix ? k_paths<false, true, kBlock, 8, true> : need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
     } else if (lds_bytes && big_blocks) {
-        if (stack)
-            kernel = has_mix ? k_paths<true, true, 1024, 6, true, K> : need_uv ? k_paths<true, true, 1024, 6, false, K> : k_paths<true, false, 1024, 6, false, K>;
-        else
-            kernel = has_mix ? k_paths<true, true, 1024, 6, true> : need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
+        kernel = has_mix ? k_paths<true, true, 1024, 6, true> : need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;
         threads = 1024;
     } else if (lds_bytes) {
-        if (stack)
-            kernel = has_mix ? k_paths<true, true, kBlock, 6, true, K> : need_uv ? k_paths<true, true, kBlock, 6, false, K> : k_paths<true, false, kBlock, 6, false, K>;
-        else
-            kernel = has_mix ? k_paths<true, true, kBlock, 6, true> : need_uv ? k_paths<true, true> : k_paths<true, false>;
+        kernel = has_mix ? k_paths<true, true, kBlock, 6, true> : need_uv ? k_paths<true, true> : k_paths<true, false>;
     } else {
-        if (stack)
-            kernel = has_mix ? k_paths<false, true, kBlock, 6, true, K> : need_uv ? k_paths<false, true, kBlock, 6, false, K> : k_paths<false, false, kBlock, 6, false, K>;
-        else
-            kernel = has_mix ? k_paths<false, true, kBlock, 6, true> : need_uv ? k_paths<false, true> : k_paths<false, false>;
+        kernel = has_mix ? k_paths<false, true, kBlock, 6, true> : need_uv ? k_paths<false, true> : k_paths<false, false>;
     }
-    if (stack) lds_bytes += (uint32_t)(K * threads * sizeof(uint2));
     if (lds_bytes > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early, spill);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
 }
 
 void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,

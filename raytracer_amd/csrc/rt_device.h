@@ -30,22 +30,35 @@ struct alignas(16) Node {
 };
 static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 
-// The same tree once more with the boxes of a node's two children stored in the node: one 64-byte record per
-// INTERIOR node, in pre-order over the interior nodes (so a left child that is interior is the next record).
-// BvhNode::hit tests both children's boxes whenever it enters a node (src/bvh.rs:302-313), so a record is read
-// whole: one 64-byte fetch per entered node instead of one 32-byte fetch per box test, and leaves need no node
-// record at all (the child reference names the primitive).
-//   q0 = left.xlo, left.xhi, left.ylo, left.yhi      q1 = left.zlo, left.zhi, right.zlo, right.zhi
-//   q2 = right.xlo, right.xhi, right.ylo, right.yhi  q3 = left ref, right ref, 0, 0
-// A child reference is the index of an interior record, or kRefLeaf | slot in the primitive table
-// (| kRefSphere for a sphere).
-struct alignas(64) WideNode {
+// The same tree once more for the stack traversal: one 128-byte record (one cache line: the unit every miss of
+// a scattered read costs, whatever part of it is used) per INTERIOR node X, indexed by X's rank among the interior
+// nodes in pre-order.  BvhNode::hit tests both children's boxes whenever it enters a node (src/bvh.rs:302-313), so
+// the record holds the boxes of X's children L and R in full, and, while they can be told, the boxes of the next
+// two levels down the left spine: the children of L and the children of L's left child LL.  A child box shares at
+// least one of each pair of opposite planes with its parent's box (a union's extreme is attained by one of its
+// parts), so a pair of children is stored as six "new" planes plus six bits saying which child inherits the
+// parent's plane and which takes the new one; the boxes come out bit for bit.  Where a pair does not have that
+// property (boxes padded differently, src/aabb.rs:78-93) the record simply stops a level earlier.  One fetch thus
+// serves up to three nodes of a left descent; right children are entered through their own records.
+//   q0 = L.xlo, L.xhi, L.ylo, L.yhi     q1 = L.zlo, L.zhi, R.zlo, R.zhi     q2 = R.xlo, R.xhi, R.ylo, R.yhi
+//   q3 = ref L, ref R, meta, 0          meta: bits 0-5 inherit mask of (LL, LR), bits 8-13 of (LLL, LLR),
+//                                             bits 16-17 levels held (1, 2 or 3)
+//   q4 = new planes of (LL, LR): xlo, xhi, ylo, yhi       q5 = their zlo, zhi | zlo, zhi of (LLL, LLR)
+//   q6 = new planes of (LLL, LLR): xlo, xhi, ylo, yhi     q7 = ref LL, ref LR, ref LLL, ref LLR
+// Plane k of the left child of a pair is the parent's when bit k of the mask is set and the new plane otherwise;
+// the right child takes the other one.  A child reference is the record index of an interior node, or
+// kRefLeaf | slot in the primitive table (| kRefSphere for a sphere).
+struct alignas(128) ChainNode {
     float lx[2], ly[2];
     float lz[2], rz[2];
     float rx[2], ry[2];
-    uint32_t left, right, pad[2];
+    uint32_t left, right, meta, pad;
+    float n1xy[4];
+    float n1z[2], n2z[2];
+    float n2xy[4];
+    uint32_t ll, lr, lll, llr;
 };
-static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+static_assert(sizeof(ChainNode) == 128, "ChainNode must be 128 bytes");
 constexpr uint32_t kRefLeaf = 0x80000000u;
 constexpr uint32_t kRefSphere = 0x40000000u;
 constexpr uint32_t kRefIndex = 0x3FFFFFFFu;
@@ -120,7 +133,7 @@ struct SceneDev {
     const TextureRec *textures;
     const uint8_t *texels;
     const uint32_t *slot_of_prim; // primitive ID -> slot in `prims` (object-list order for World::hit)
-    const WideNode *wide;         // n_prims - 1 records; nullptr when the table was not built
+    const ChainNode *chain;       // n_prims - 1 records; nullptr when the table was not built
     uint32_t root_ref;            // child reference of the root (a leaf reference for a one-primitive scene)
     uint32_t depth;               // levels of the tree: the traversal stack never holds more than depth - 1 entries
     uint32_t n_nodes;

@@ -694,7 +694,7 @@ def test_config5_soup_ten_million_triangles_full_size(gpu_ctx):
     r = Renderer(cam, scene, rs)
     a = r.render_sums()
     st = r.last_stats
-    assert st.pipeline == F.RT_PIPELINE_PATHS
+    assert st.pipeline == F.RT_PIPELINE_LANES
     b = r.render_sums()
     assert bits_equal(a, b).all(), "two runs must be bit-identical"
     assert st.paths == w * h * 2 and st.rays_traced == r.last_stats.rays_traced

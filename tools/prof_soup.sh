@@ -1,9 +1,8 @@
 #!/bin/bash
-# PMC passes (memory side) for the 10 M soup with one traversal: tools/prof_soup.sh OUTDIR walk|stack
-OUT=$1; T=$2
+# PMC passes (memory side) for the 10 M soup: RT_PIPE=<pipeline> tools/prof_soup.sh OUTDIR
+OUT=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-export RT_TRAVERSAL=$T
 i=0
 for p in "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_READ_sum GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_READ_sum SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES"; do
   timeout -s KILL 150 rocprofv3 --pmc $p --output-format csv -d "$OUT/pass$i" -o pmc -- python3 tools/quick_bench.py soup10000000 1920 1080 32 1 ${RT_PIPE:-0} 134217728 > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -n 5 "$OUT/pass$i.log"; [ $i -eq 2 ] || exit 1; }
