@@ -9,11 +9,18 @@ on the device.  One ray = one closest-hit query (`world.hit`, src/renderer.rs:44
     python bench.py [--gpus N] [--steps K] [--warmup W]
 N > 1 runs one rank per GPU: either a launcher (torch.distributed.run) has started the N ranks, or bench.py
 starts them itself as a child process.
+
+At N = 1 the same run also times the other configurations (teapot, 485 spheres, 10 M triangle soup: `legs` in
+the JSON line), each with its own roofline, and the CPU oracle on the host cores (`cpu_baseline`).
+
+    python bench.py --profile-leg NAME      three launches of that leg's reference workload (samples [0, spp)),
+                                            the program rocprofv3 is pointed at (tools/prof_legs.sh)
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -28,17 +35,200 @@ import torch
 
 WIDTH, HEIGHT, MAX_DEPTH, SEED = 1920, 1080, 50, 1  # --width / --height override the size for rehearsals only
 SPP_PER_STEP = 64
-MAX_PATHS = 1 << 27          # path slots per batch: the 64 samples of a 1080p frame a step renders (11.8 GB of state)
-TIMED_BOUNCES = 6            # extend launches bracketed by HIP events per batch (they carry > 98 % of the rays)
+MAX_PATHS = 1 << 27          # path slots per batch: the 64 samples of a 1080p frame a step renders
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; the chip's maximum shader clock
+VALU_PEAK = SIMDS * CLOCK_HZ / 4.0  # wave64 VALU instructions per second: one per SIMD every four cycles
+PIPELINES = {1: "split", 2: "fused", 3: "fused+lds", 4: "hybrid", 5: "hybrid+lds", 6: "split+lds", 7: "paths",
+             8: "paths+lds", 9: "lanes"}
+
+# The configurations of the metric: (spp per launch, background).  Every launch of a leg renders the same samples
+# [0, spp), so launches are identical and comparable with the profiled ones.
+LEGS = {
+    "cornell": (SPP_PER_STEP, (0.0, 0.0, 0.0)),
+    "teapot": (SPP_PER_STEP, (0.0, 0.0, 0.0)),        # the reference's asset as it would run it: default camera
+    "teapot_lit": (SPP_PER_STEP, (0.0, 0.0, 0.0)),    # the same mesh with a light and a camera outside it
+    "spheres": (SPP_PER_STEP, (0.7, 0.8, 1.0)),
+    "soup10m": (32, (0.0, 0.0, 0.0)),
+}
 
 
-def cpu_baseline(desc, cam_settings, threads):
+def source_digest():
+    """Digest of the kernel sources: a committed PMC profile only speaks for the build it was taken from."""
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "rt_math.h", "rt_device.h", "kernels.h"):
+        h.update(open(os.path.join(ROOT, "raytracer_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def leg_scene(name):
+    from raytracer_amd import load_from_gltf
+    from raytracer_amd.scenes import lit_teapot, rtiow_final_scene, triangle_soup
+
+    if name == "cornell":
+        desc = load_from_gltf(os.path.join(ROOT, "assets", "cornell.gltf"))
+        return desc, desc.camera(0), "assets/cornell.gltf Cornell box"
+    if name in ("teapot", "teapot_lit"):
+        desc = load_from_gltf(os.path.join(ROOT, "assets", "teapot.gltf"))
+        if name == "teapot":
+            return desc, desc.camera(0), ("assets/teapot.gltf, 9128 triangles, default camera (no light: black image, "
+                                          "every path traced)")
+        desc, cs = lit_teapot(desc)
+        return desc, cs, "assets/teapot.gltf + a 30x30 light, camera at (0, 10, 60)"
+    if name == "spheres":
+        desc, cs = rtiow_final_scene()
+        return desc, cs, ("RTIOW final scene, 485 spheres (lambertian / metal / dielectric), defocus, "
+                          "background (0.7, 0.8, 1.0)")
+    if name == "soup10m":
+        desc, cs = triangle_soup(10_000_000)
+        return desc, cs, "synthetic soup of 10 000 000 triangles (0.1 % emitters), incoherent diffuse bounces"
+    raise SystemExit(f"unknown leg {name}")
+
+
+def committed_profile(name, kernel_hint, rays_per_launch):
+    """The PMC figures of profiles/r02_pmc_<leg>.json, or (None, reason) when they do not describe this build and
+    this workload: the kernel sources must hash the same and the profiled launch must have traced the same rays."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_{name}.json")
+    if not os.path.exists(path):
+        return None, "no committed PMC profile"
+    p = json.load(open(path))
+    if p.get("source_digest") != source_digest():
+        return None, (f"stale PMC profile: taken from kernel sources {p.get('source_digest')}, this build is "
+                      f"{source_digest()}")
+    if int(p.get("rays_per_dispatch", -1)) != int(rays_per_launch):
+        return None, f"stale PMC profile: {p.get('rays_per_dispatch')} rays per dispatch there, {rays_per_launch} here"
+    if kernel_hint not in p.get("kernel", ""):
+        return None, f"stale PMC profile: kernel {p.get('kernel')!r}, expected {kernel_hint}"
+    return p, os.path.relpath(path, ROOT)
+
+
+def run_leg(name, device, launches, warmup=1, width=None, height=None, want_counts=True):
+    """Times `launches` identical launches of one configuration (samples [0, spp) of every pixel) with HIP events on
+    the context's stream, and counts box / primitive tests per ray with the instrumented kernels."""
+    from raytracer_amd import RenderSettings, _ffi as F
+    from raytracer_amd.renderer import Context, Scene, camera_from_settings
+
+    w, h = width or WIDTH, height or HEIGHT
+    spp, bg = LEGS[name]
+    t0 = time.perf_counter()
+    desc, cs, what = leg_scene(name)
+    dev = torch.device("cuda", device)
+    ctx = Context(device, flags=F.RT_CTX_TIMING)
+    ctx.set_max_paths(MAX_PATHS)
+    scene = Scene(ctx, desc)
+    info = scene.info()
+    setup_s = time.perf_counter() - t0
+    cam = camera_from_settings(cs, w, h)
+    lib = ctx.lib
+    rs = RenderSettings(w, h, 0, MAX_DEPTH, spp, bg, F.RT_MODE_GAMMA_PER_SAMPLE, SEED).to_c()
+    buf = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    stats = []
+    wall0 = time.perf_counter()
+    for i in range(warmup + launches):
+        if i == warmup:
+            ctx.synchronize()
+            wall0 = time.perf_counter()
+        st = F.rt_stats()
+        F.check(lib, lib.rt_render_device(ctx.handle, scene.handle, C.byref(cam), C.byref(rs), C.c_void_p(buf.data_ptr()),
+                                          C.byref(st)))
+        if i >= warmup:
+            stats.append(st)
+    ctx.synchronize()
+    wall = time.perf_counter() - wall0
+    rays = stats[0].rays_traced
+    assert all(s.rays_traced == rays for s in stats), "identical launches must trace identical rays"
+    kernel_ms = sum(s.bounce_ms + s.extend_ms + s.shade_ms + s.generate_ms for s in stats) / launches
+    total_ms = sum(s.total_ms for s in stats) / launches
+    out = {"workload": f"{what}; {w}x{h}, depth {MAX_DEPTH}, {spp} spp per launch, progressive (gamma per sample)",
+           "triangles": info.num_triangles, "spheres": info.num_spheres, "bvh_nodes": info.num_nodes, "bvh_depth": info.depth,
+           "scene_bytes_in_hbm": info.device_bytes, "scene_setup_s": setup_s,
+           "pipeline": PIPELINES.get(stats[0].pipeline, str(stats[0].pipeline)), "launches": launches,
+           "rays_per_launch": rays, "paths_per_launch": stats[0].paths, "rays_per_path": rays / stats[0].paths,
+           "ms_per_launch": total_ms, "render_kernel_ms_per_launch": kernel_ms, "wall_ms_per_launch": wall / launches * 1e3,
+           "mrays_per_s": rays / (total_ms * 1e-3) / 1e6}
+    del buf
+    scene.close()
+    ctx.close()
+    if want_counts:
+        # box and primitive tests per ray (BVH2-equivalent visits, as the reference's recursion makes them), counted by
+        # the instrumented extend kernel on a few samples of the same frame
+        cctx = Context(device, flags=F.RT_CTX_COUNTERS)
+        cscene = Scene(cctx, desc)
+        n_count = 4 if info.num_nodes < 1_000_000 else 1
+        crs = RenderSettings(w, h, 0, MAX_DEPTH, n_count, bg, F.RT_MODE_GAMMA_PER_SAMPLE, SEED).to_c()
+        cbuf = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+        st = F.rt_stats()
+        F.check(lib, lib.rt_render_device(cctx.handle, cscene.handle, C.byref(cam), C.byref(crs), C.c_void_p(cbuf.data_ptr()),
+                                          C.byref(st)))
+        n, t, s = (st.node_visits / st.rays_traced, st.triangle_tests / st.rays_traced, st.sphere_tests / st.rays_traced)
+        # per ray: 32 B ray + 16 B hit + 32 B per box test + 36 B per triangle test + 16 B per sphere test, plus 80 B of
+        # path state per segment
+        out.update({"box_tests_per_ray": n, "triangle_tests_per_ray": t, "sphere_tests_per_ray": s,
+                    "algorithmic_bytes_per_ray": 32 + 16 + 32 * n + 36 * t + 16 * s + 80})
+        del cbuf
+        cscene.close()
+        cctx.close()
+    return out
+
+
+def roofline_of(name, leg):
+    """The roofline of a leg's render kernel.  Scenes whose tables live in LDS or the L2s are bound by VALU issue
+    (wave-level instructions per second against one per SIMD every four cycles); the soup is bound by HBM.  The
+    instruction and traffic counts come from the committed PMC profile of the same build and the same launch."""
+    kernel_hint = {"lanes": "k_paths_lanes", "paths": "k_paths", "paths+lds": "k_paths"}.get(leg["pipeline"], "k_")
+    prof, origin = committed_profile(name, kernel_hint, leg["rays_per_launch"])
+    secs = leg["render_kernel_ms_per_launch"] * 1e-3
+    alg_gbs = leg["algorithmic_bytes_per_ray"] * leg["rays_per_launch"] / secs / 1e9
+    hbm_bound = name == "soup10m"
+    r = {"kernel": prof["kernel"] if prof else kernel_hint, "avg_launch_ms": leg["render_kernel_ms_per_launch"],
+         "rays_per_launch": leg["rays_per_launch"], "algorithmic_bytes_per_ray": leg["algorithmic_bytes_per_ray"],
+         "algorithmic_gbs": alg_gbs, "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+         "pmc": origin if prof else None, "pmc_status": "matches this build and this launch" if prof else origin}
+    traffic = None
+    if prof:
+        d = prof["per_ray"]
+        traffic = (d["hbm_read_bytes"] + d["hbm_write_bytes"]) * leg["rays_per_launch"]
+        r.update({"hbm_bytes_per_ray": d["hbm_read_bytes"] + d["hbm_write_bytes"],
+                  "hbm_traffic_gbs": traffic / secs / 1e9, "hbm_traffic_frac_of_peak": traffic / secs / 1e9 / HBM_PEAK_GBS,
+                  "valu_wave_instructions_per_ray": d["valu_wave_instructions"], "lane_utilisation": prof["lane_utilisation"],
+                  "l2_requests_per_ray": d.get("l2_read_requests"), "l2_misses_per_ray": d.get("hbm_read_requests"),
+                  "rocprof_avg_launch_ms": prof.get("avg_dispatch_ms")})
+    if hbm_bound:
+        r.update({"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+                  "traffic": traffic})
+    elif prof:
+        ach = prof["per_ray"]["valu_wave_instructions"] * leg["rays_per_launch"] / secs
+        r.update({"bound": "valu", "achieved": ach / 1e9, "peak": VALU_PEAK / 1e9, "unit": "G wave-instructions/s",
+                  "frac": ach / VALU_PEAK, "traffic": traffic,
+                  "peak_is": f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz / 4 cycles per wave64 VALU instruction"})
+    else:
+        r.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave-instructions/s", "frac": None,
+                  "traffic": None})
+    r["traffic_unit"] = "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; a read request is one 128-byte line)"
+    return r
+
+
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may run on (the GPU box gives a job a share of a larger
+    machine and says so through OMP_NUM_THREADS)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and 0 < int(share) < n:
+        n = int(share)
+    return max(1, n)
+
+
+def cpu_baseline(desc, cam_settings):
     """The oracle (CPU restatement of the reference algorithm, NOT the Rust binary) timed on the host cores
     on a bounded sample of the same workload: the same 1920x1080 Cornell frame at reduced spp."""
     from oracle import binding as ob
     from raytracer_amd import RenderSettings, _ffi as F
 
+    threads = host_threads()
     oracle = ob.OracleScene(desc)
     cam = ob.camera_from_settings(cam_settings, WIDTH, HEIGHT)
     rs = RenderSettings(WIDTH, HEIGHT, 0, MAX_DEPTH, 1, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=SEED)
@@ -50,7 +240,13 @@ def cpu_baseline(desc, cam_settings, threads):
     t0 = time.time()
     _, st = oracle.render(cam, rs, threads=threads, rng_mode=ob.RNG_THREAD)
     dt = time.time() - t0
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
     return {"value": st.rays_traced / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "host": {"os_cpu_count": os.cpu_count(), "cpus_in_affinity_mask": affinity,
+                     "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")},
             "sample": f"Cornell {WIDTH}x{HEIGHT}, {spp} spp, depth {MAX_DEPTH}, {st.rays_traced} rays in {dt:.2f} s; "
                       "CPU restatement of the reference algorithm (per-thread xoshiro256++, 256-pixel chunks), "
                       "not the Rust binary"}
@@ -64,6 +260,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the teapot / spheres / soup legs")
+    ap.add_argument("--profile-leg", default=None, help="run three launches of one leg's reference workload and exit")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo is for rehearsals")
     ap.add_argument("--share-device0", action="store_true",
                     help="rehearsal on a one-GPU box: every rank renders on cuda:0 (use with --backend gloo)")
@@ -89,6 +287,15 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_device0 else int(os.environ.get("LOCAL_RANK", "0"))
+    WIDTH, HEIGHT = args.width, args.height
+
+    if args.profile_leg:
+        torch.cuda.set_device(0)
+        leg = run_leg(args.profile_leg, 0, launches=3, warmup=0, want_counts=False)
+        leg["source_digest"] = source_digest()
+        print(json.dumps({"profile_leg": args.profile_leg, **leg}))
+        return
+
     if world > 1:
         import torch.distributed as dist
 
@@ -104,8 +311,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    WIDTH, HEIGHT = args.width, args.height
-
     from raytracer_amd import RenderSettings, _ffi as F, load_from_gltf
     from raytracer_amd.distributed import sample_range
     from raytracer_amd.renderer import Context, Scene, camera_from_settings
@@ -115,7 +320,6 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = Context(local_rank, stream=stream.cuda_stream, flags=F.RT_CTX_TIMING)
     ctx.set_max_paths(MAX_PATHS)
-    ctx.set_timed_bounces(TIMED_BOUNCES)
     scene = Scene(ctx, desc)
     cam = camera_from_settings(desc.camera(0), WIDTH, HEIGHT)
     lib = ctx.lib
@@ -127,9 +331,8 @@ def main():
     # already renders into the other one.
     step_bufs = [torch.zeros(npix * 3, dtype=torch.float32, device=dev) for _ in range(2)]
     pending = [None, None]
-    acc = {"rays": 0, "paths": 0, "bounce_ms": 0.0, "extend_ms": 0.0, "timed_rays": 0, "timed_launches": 0,
-           "gpu_ms": 0.0, "shade_ms": 0.0, "generate_ms": 0.0, "accumulate_ms": 0.0, "pipeline": 0,
-           "first_ms": 0.0, "first_rays": 0, "first_launches": 0}
+    acc = {"rays": 0, "paths": 0, "render_ms": 0.0, "timed_rays": 0, "timed_launches": 0, "gpu_ms": 0.0,
+           "accumulate_ms": 0.0, "pipeline": 0}
 
     def retire(slot: int):
         """Wait for the all-reduce of buffer `slot` (if any) and fold it into the running total."""
@@ -158,17 +361,11 @@ def main():
             acc["rays"] += st.rays_traced
             acc["paths"] += st.paths
             acc["gpu_ms"] += st.total_ms
-            acc["bounce_ms"] += st.bounce_ms
-            acc["extend_ms"] += st.extend_ms
-            acc["shade_ms"] += st.shade_ms
-            acc["generate_ms"] += st.generate_ms
+            acc["render_ms"] += st.bounce_ms + st.extend_ms + st.shade_ms + st.generate_ms
             acc["accumulate_ms"] += st.accumulate_ms
-            acc["timed_rays"] += st.timed_bounce_rays
-            acc["timed_launches"] += st.timed_bounce_launches
+            acc["timed_rays"] += st.timed_bounce_rays + st.timed_extend_rays
+            acc["timed_launches"] += max(1, st.timed_bounce_launches)
             acc["pipeline"] = st.pipeline
-            acc["first_ms"] += st.first_bounce_ms
-            acc["first_rays"] += st.first_bounce_rays
-            acc["first_launches"] += st.first_bounce_launches
 
     for i in range(args.warmup):
         step(i, False)
@@ -199,77 +396,27 @@ def main():
         rays_all, paths_all = acc["rays"], acc["paths"]
 
     if rank == 0:
-        # per-ray algorithmic bytes of the extend kernel from an instrumented pass (outside the timed region):
-        # 32 B ray read + 16 B hit write + 32 B per box test + 36 B per triangle test + 16 B per sphere test.
-        cctx = Context(local_rank, flags=F.RT_CTX_COUNTERS)
-        cscene = Scene(cctx, desc)
-        rs = RenderSettings(WIDTH, HEIGHT, 0, MAX_DEPTH, 4, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=SEED).to_c()
-        buf = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
-        st = F.rt_stats()
-        F.check(lib, lib.rt_render_device(cctx.handle, cscene.handle, C.byref(cam), C.byref(rs),
-                                          C.c_void_p(buf.data_ptr()), C.byref(st)))
-        nodes_per_ray = st.node_visits / st.rays_traced
-        tris_per_ray = st.triangle_tests / st.rays_traced
-        sph_per_ray = st.sphere_tests / st.rays_traced
-        # + 80 B of path state per segment (throughput, radiance, pixel, depth/flags, rng; read and written)
-        bytes_per_ray = 32 + 16 + 32 * nodes_per_ray + 36 * tris_per_ray + 16 * sph_per_ray + 80
-        cscene.close()
-        cctx.close()
-
-        # HBM bytes per ray of the same kernel from the committed PMC run (FETCH_SIZE x2 + WRITE_SIZE)
-        traffic_per_ray = None
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic_cornell1080p.json")
-        if os.path.exists(tj):
-            kernels = json.load(open(tj)).get("kernels", {})
-            kern = kernels.get("k_paths") or kernels.get("k_bounce")
-            if kern:
-                traffic_per_ray = kern["hbm_read_bytes_per_ray"] + kern["hbm_write_bytes_per_ray"]
-
-        # VALU picture of the same kernel from the committed PMC run (the kernel is instruction-issue bound, which the
-        # HBM roofline above cannot show): wave-level VALU instructions per ray, VALU-busy share of SIMD cycles
-        # (4 cycles per wave64 instruction, 1024 SIMDs, GRBM_GUI_ACTIVE summed over the 8 XCDs) and lane utilisation.
-        valu = None
-        pj = os.path.join(ROOT, "profiles", "r01_v8_pmc_summary_cornell1080p_paths_lds.txt")
-        if os.path.exists(pj) and os.path.exists(tj):
-            vals, on = {}, False
-            for line in open(pj):
-                if not line.startswith(" "):
-                    on = "k_paths" in line
-                elif on:
-                    parts = line.split()
-                    vals[parts[0]] = float(parts[1])
-            pmc_rays = json.load(open(tj)).get("rays", 0)
-            if pmc_rays and "SQ_INSTS_VALU" in vals:
-                simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-                valu = {"wave_instructions_per_ray": vals["SQ_INSTS_VALU"] / pmc_rays,
-                        "busy_share_of_simd_cycles": 4.0 * vals["SQ_ACTIVE_INST_VALU"] / simd_cycles,
-                        "lane_utilisation": vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_INSTS_VALU"]),
-                        "source": "profiles/r01_v8_pmc_summary_cornell1080p_paths_lds.txt (PMC, not measured in this run; "
-                                  "the busy share divides counters of two profiling passes and reads slightly above 1 when "
-                                  "the VALUs are saturated)"}
-
-        # The fused kernel has two instances: k_bounce<FIRST=true> (bounce 0: camera rays generated in place) and
-        # k_bounce<FIRST=false> (later bounces).  Later bounces dominate the time; bounces 1..TIMED_BOUNCES-1 of every
-        # batch are bracketed by events here, bounce 0 separately.
-        def group(ms, rays, launches):
-            avg_ms = ms / max(1, launches)
-            per_launch = rays / max(1, launches)
-            ach = bytes_per_ray * per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            return avg_ms, per_launch, ach
-
-        later = group(acc["bounce_ms"] - acc["first_ms"], acc["timed_rays"] - acc["first_rays"],
-                      acc["timed_launches"] - acc["first_launches"])
-        first = group(acc["first_ms"], acc["first_rays"], acc["first_launches"])
-        avg_launch_ms, rays_per_launch, achieved = later
-        one_launch_per_batch = acc["pipeline"] in (F.RT_PIPELINE_PATHS, F.RT_PIPELINE_PATHS_LDS)
-        if one_launch_per_batch:
-            kernel_name = ("k_paths<true,false> (one launch per batch of %d spp: generate + extend + shade of every bounce; "
-                           "BVH and triangles staged in LDS)" % min(spp, MAX_PATHS // npix))
-        else:
-            kernel_name = ("k_bounce<false,true,false> (extend + shade of bounces 1..%d of each batch, BVH and triangles "
-                           "staged in LDS)" % (TIMED_BOUNCES - 1))
         img = (total / float(spp * world * (args.steps + args.warmup))).cpu().numpy()
         finite = np.isfinite(img)
+        full_size = (WIDTH, HEIGHT, spp) == (1920, 1080, SPP_PER_STEP)
+        scene.close()
+        ctx.close()
+        del step_bufs, total
+        torch.cuda.empty_cache()
+        # The headline kernel's roofline.  Timing: HIP events around the render launches of the timed steps, on the
+        # context's stream.  Instruction and traffic counts per ray: the committed PMC profile, accepted only if it was
+        # taken from these kernel sources on a launch that traced exactly the rays the reference launch (samples
+        # [0, spp)) traces in this run.
+        ref = run_leg("cornell", local_rank, launches=2, warmup=1, width=WIDTH, height=HEIGHT)
+        avg_ms = acc["render_ms"] / max(1, acc["timed_launches"])
+        # the timed steps render later sample ranges than the reference launch: their ray counts differ by < 0.1 %
+        roof = roofline_of("cornell" if full_size else "rehearsal", {**ref, "render_kernel_ms_per_launch": avg_ms})
+        roof.update({"timed_launches": acc["timed_launches"],
+                     "rays_per_timed_launch": acc["timed_rays"] / max(1, acc["timed_launches"]),
+                     "box_tests_per_ray": ref["box_tests_per_ray"], "triangle_tests_per_ray": ref["triangle_tests_per_ray"],
+                     "note": "Cornell's BVH and triangles (4 KB) are staged in LDS: the algorithmic bytes never leave the CU, "
+                             "so the kernel is bound by VALU issue, not by HBM; frac = wave-level VALU instructions per "
+                             "second over the SIMDs' issue rate, algorithmic_gbs is the figure the byte formula gives"})
         out = {
             "metric": "Mrays/s per GPU and per node (1/2/4/8), Cornell 1080p; time to 1024 spp",
             "value": rays_all / elapsed / 1e6,
@@ -292,32 +439,24 @@ def main():
             "mpaths_per_s": paths_all / elapsed / 1e6,
             "rays_per_path": rays_all / max(1, paths_all),
             "time_to_1024spp_s": 1024.0 * npix / (paths_all / elapsed),
-            "pipeline": {2: "fused", 3: "fused+lds", 7: "paths", 8: "paths+lds"}.get(acc["pipeline"], str(acc["pipeline"])),
-            "kernel_ms_rank0": {k: acc[k] for k in ("gpu_ms", "bounce_ms", "generate_ms", "extend_ms", "shade_ms",
-                                                    "accumulate_ms")},
+            "pipeline": PIPELINES.get(acc["pipeline"], str(acc["pipeline"])),
+            "kernel_ms_rank0": {"gpu_ms": acc["gpu_ms"], "render_kernels_ms": acc["render_ms"],
+                                "accumulate_ms": acc["accumulate_ms"]},
             "image_check": {"finite_mean": float(img[finite].mean()), "inf_fraction": float(np.isinf(img).mean()),
                             "nan_fraction": float(np.isnan(img).mean())},
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None if traffic_per_ray is None else traffic_per_ray * rays_per_launch,
-                "traffic_unit": "bytes per launch (HBM, PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_cornell1080p.json)",
-                "kernel": kernel_name,
-                "avg_launch_ms": avg_launch_ms, "rays_per_launch": rays_per_launch,
-                "first_bounce_kernel": None if one_launch_per_batch else {
-                    "kernel": "k_bounce<true,true,false> (generate + extend + shade of bounce 0)",
-                    "avg_launch_ms": first[0], "rays_per_launch": first[1], "achieved": first[2],
-                    "frac": first[2] / HBM_PEAK_GBS, "launches": acc["first_launches"]},
-                "valu": valu,
-                "algorithmic_bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
-                "triangle_tests_per_ray": tris_per_ray, "timed_launches": acc["timed_launches"] - acc["first_launches"],
-                "note": "Cornell's BVH + triangles are 4 KB and are read from LDS: of the algorithmic bytes only the path "
-                        "state reaches HBM (see traffic), so frac is an on-chip bandwidth figure quoted against the HBM "
-                        "peak as the contract asks; the kernel is VALU-issue bound (profiles/r01_pmc_summary_*.txt)",
-            },
+            "roofline": roof,
+            "kernel_source_digest": source_digest(),
         }
+        if world == 1 and not args.no_legs and full_size:
+            legs = {}
+            for name in ("teapot", "teapot_lit", "spheres", "soup10m"):
+                leg = run_leg(name, local_rank, launches=3 if name != "soup10m" else 2, warmup=1)
+                leg["roofline"] = roofline_of(name, leg)
+                legs[name] = leg
+                torch.cuda.empty_cache()
+            out["legs"] = legs
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(desc, desc.camera(0), threads=min(16, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(desc, desc.camera(0))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
