@@ -8,6 +8,12 @@
 //!     `TriangleMeshData::{vertices, face_indices, normals, uv, material}` as `pub(crate)`
 //!     (src/object/triangle_mesh.rs:12-18,84-102)
 //!   - `Sphere::{center, radius, material}` as `pub(crate)` (src/object/sphere.rs:11-18)
+//!   - `Checkerboard::{inv_scale(&self) -> f32, even(&self) -> &Arc<Texture>, odd(&self) -> &Arc<Texture>}`
+//!     (src/texture.rs:54-58) and `Image::image(&self) -> &DynamicImage` (src/texture.rs:85-87)
+//! The material structs' fields (`Lambertian::texture`, `Metal::{texture, fuzz}`, `Dielectric::refraction_index`,
+//! `DiffuseLight::{texture, strength}`, `Mix::{left, right, factor}`, `TrowbridgeReitz::roughness`) and
+//! `SolidColor::albedo` are already `pub` (src/material.rs:43-46,67-70,85-87,124-127,179-184,207-209;
+//! src/texture.rs:43-45).
 //! and it must be handed the scene BEFORE `build_bvh` (the library builds the same tree itself,
 //! src/bvh.rs:248-285), i.e. `main` skips `scene.build_bvh(...)` when this renderer is selected.
 use std::collections::HashMap;
@@ -95,7 +101,7 @@ impl Flattened {
             Material::Dielectric(d) => { rec.kind = sys::RT_MAT_DIELECTRIC; rec.param = d.refraction_index; }
             Material::DiffuseLight(d) => {
                 rec.kind = sys::RT_MAT_DIFFUSE_LIGHT;
-                rec.texture = self.texture(&Arc::new(d.texture.clone_solid()));
+                rec.texture = self.texture(&d.texture);
                 rec.param = d.strength;
             }
             Material::Mix(x) => {

@@ -39,7 +39,10 @@ void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
                   uint32_t cap, uint32_t *queue0, uint32_t *queue1, uint32_t *counts, uint32_t *early, bool need_uv,
                   bool has_mix, uint32_t lds_bytes, bool big_blocks, bool eight_waves);
 // Entries per lane of the stack traversal's stack that live in LDS; deeper ones go to the spill area.
-constexpr int kStackEntriesInLds = 8;
+#ifndef RT_STACK_K
+#define RT_STACK_K 8
+#endif
+constexpr int kStackEntriesInLds = RT_STACK_K;
 // One lane per path (k_paths_lanes): the whole batch in one launch without queues or path state in device
 // memory, for scenes read from HBM; needs sc.chain.  `ray_counts[b]` receives the rays block b traced beyond each
 // path's first.  `waves`: waves per SIMD the register budget is set for (4, 6 or 8).

@@ -11,6 +11,10 @@
 #include "kernels.h"
 #include "rt_math.h"
 
+#ifndef RT_SERVICE_DIV
+#define RT_SERVICE_DIV 4u
+#endif
+
 namespace rt {
 
 namespace {
@@ -1210,7 +1214,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
         // a quarter of the wave, or when nothing else is left to do.
         const uint32_t idle = n_fin + (exhausted ? 0u : n_empty);
         const uint32_t usable = 64u - (exhausted ? n_empty : 0u);
-        if (n_busy == 0u || idle * 4u >= usable) {
+        if (n_busy == 0u || idle * RT_SERVICE_DIV >= usable) {
             if (n_fin && finished) {
                 V3 l;
                 g.o = walk.o;

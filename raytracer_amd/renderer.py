@@ -117,7 +117,8 @@ def pixels_to_rgb8(pixels: np.ndarray) -> np.ndarray:
     """`pixels_to_image` (src/renderer.rs:173-176): Rgb32F -> Rgb8 as the `image` crate converts it,
     round(clamp(c, 0, 1) * 255); NaN becomes 0."""
     p = np.nan_to_num(np.asarray(pixels, dtype=np.float32), nan=0.0, posinf=1.0, neginf=0.0)
-    return np.rint(np.clip(p, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    # Rust's f32::round rounds halves away from zero (np.rint would round them to even)
+    return np.floor(np.clip(p, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
 
 
 class Renderer:

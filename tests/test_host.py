@@ -186,6 +186,30 @@ def test_progressive_schedule_and_rgb8():
     assert pixels_to_rgb8(px).tolist() == [0, 128, 255, 255, 0, 0, 255]
 
 
+def test_rgb8_rounds_halves_away_from_zero_in_both_host_layers():
+    """`pixels_to_image` (src/renderer.rs:173-176) goes through the `image` crate's f32 -> u8 conversion,
+    round(clamp(c, 0, 1) * 255) with Rust's `round` (halves away from zero).  Values whose product with 255 is
+    exactly k + 0.5 in binary32 must give k + 1 in the Python sink and in the C++ one (rt_host.hpp)."""
+    k = np.arange(255, dtype=np.float32)
+    c = ((k + np.float32(0.5)) / np.float32(255.0)).astype(np.float32)
+    exact = (c * np.float32(255.0)) == k + np.float32(0.5)
+    assert exact.sum() > 20 and (k[exact] % 2 == 0).any()  # even k is where round-half-to-even would differ
+    want = (k[exact] + 1).astype(np.uint8)
+    assert np.array_equal(pixels_to_rgb8(c[exact]), want)
+    src = r"""
+#include "raytracer_amd/csrc/host/rt_host.hpp"
+int main() { std::vector<float> px; float f; while (fread(&f, 4, 1, stdin) == 1) px.push_back(f);
+  std::vector<uint8_t> o = rt::host::pixels_to_rgb8(px); fwrite(o.data(), 1, o.size(), stdout); return 0; }
+"""
+    with tempfile.TemporaryDirectory() as td:
+        cpp, exe = os.path.join(td, "rgb8.cpp"), os.path.join(td, "rgb8")
+        open(cpp, "w").write(src)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", ROOT, cpp, "-o", exe, "-L", os.path.dirname(F.LIB_PATH),
+                               "-lrt_mi355x", "-lz", "-Wl,-rpath," + os.path.dirname(F.LIB_PATH)])
+        out = subprocess.run([exe], input=c[exact].tobytes(), capture_output=True, check=True).stdout
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint8), want)
+
+
 def test_render_settings_defaults_match_cli():
     """Defaults of the reference CLI (src/main.rs:46-59,86): 1280x720, depth 50, 100 spp, black background."""
     rs = RenderSettings()
