@@ -49,7 +49,7 @@ LEGS = {
     "teapot": (SPP_PER_STEP, (0.0, 0.0, 0.0)),        # the reference's asset as it would run it: default camera
     "teapot_lit": (SPP_PER_STEP, (0.0, 0.0, 0.0)),    # the same mesh with a light and a camera outside it
     "spheres": (SPP_PER_STEP, (0.7, 0.8, 1.0)),
-    "soup10m": (32, (0.0, 0.0, 0.0)),
+    "soup10m": (64, (0.0, 0.0, 0.0)),
 }
 
 

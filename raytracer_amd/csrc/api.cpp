@@ -219,7 +219,7 @@ template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **ds
     *dst = nullptr;
     size_t n = v.size() ? v.size() : 1;
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, n * sizeof(T) + 128)); // slack: the stack traversal reads 128 bytes at a 48-byte record
+    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
     s->blocks[s->n_blocks++] = p;
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T *>(p);
