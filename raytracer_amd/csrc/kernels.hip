@@ -14,6 +14,9 @@
 #ifndef RT_SERVICE_DIV
 #define RT_SERVICE_DIV 4u
 #endif
+#ifndef RT_LEAF_DIV
+#define RT_LEAF_DIV 4u
+#endif
 
 namespace rt {
 
@@ -301,60 +304,79 @@ struct StackWalk {
         hit_r = !(min_raw(best.t, xr) <= er);
     }
 
-    __device__ __forceinline__ void step(const float4 *__restrict__ chain, const float4 *__restrict__ prims) {
-        const bool leaf = (cur & kRefLeaf) != 0u;
-        const uint32_t index = cur & kRefIndex;
-        // one memory round per step whatever the lanes hold: the 48 bytes of a primitive, or the 128 bytes of a node
-        // record (its other five quads are loaded by the node lanes only: a primitive record read any further would
-        // reach into the next cache line more often).  Measured and rejected: primitive records at a 64-byte stride,
-        // which never straddle a line but pack fewer neighbouring leaves into one (10 M soup 0.44 -> 0.40 Grays/s).
-        const float4 *__restrict__ p = leaf ? prims + 3 * (size_t)index : chain + 8 * (size_t)index;
-        const float4 a = p[0], b = p[1], c = p[2];
-        uint32_t next = kRefNone;
-        if (leaf) {
-            if (cur & kRefSphere)
-                sphere_test(a, index, o, d, tmin, best);
-            else
-                tri_test(a, b, c, index, o, d, tmin, best);
-        } else {
-            const float4 q = p[3], n1 = p[4], nz = p[5], n2 = p[6], refs = p[7];
-            const uint32_t meta = f2u(q.z);
-            const uint32_t levels = meta >> 16;
-            float el, xl, er, xr;
-            slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, el, xl);
-            slab_pair(c.x, c.y, c.z, c.w, b.z, b.w, o, inv, tmin, er, xr);
-            bool hit_l = !(min_raw(best.t, xl) <= el);
-            bool hit_r = !(min_raw(best.t, xr) <= er);
-            if (hit_r && hit_l) stack.push(er, f2u(q.y));
-            if (!hit_l) {
-                if (hit_r) next = f2u(q.y);
-            } else if (levels < 2u) {
-                next = f2u(q.x);
-            } else { // L's children, from L's box
-                float box[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
-                const float fresh1[6] = {n1.x, n1.y, n1.z, n1.w, nz.x, nz.y};
-                pair_below(box, fresh1, meta, hit_l, hit_r, er);
-                if (hit_r && hit_l) stack.push(er, f2u(refs.y));
-                if (!hit_l) {
-                    if (hit_r) next = f2u(refs.y);
-                } else if (levels < 3u) {
-                    next = f2u(refs.x);
-                } else { // LL's children, from LL's box
-                    const float fresh2[6] = {n2.x, n2.y, n2.z, n2.w, nz.z, nz.w};
-                    pair_below(box, fresh2, meta >> 8, hit_l, hit_r, er);
-                    if (hit_r && hit_l) stack.push(er, f2u(refs.w));
-                    if (hit_l)
-                        next = f2u(refs.z);
-                    else if (hit_r)
-                        next = f2u(refs.w);
-                }
-            }
-        }
+    // After a step: `next` if the step named a node to go on with, else the most recent pending right child that
+    // still passes with the present closest distance.
+    __device__ __forceinline__ void advance(uint32_t next) {
         while (next == kRefNone && stack.sp > 0u) {
             const uint2 e = stack.pop();
             if (!(best.t <= u2f(e.x))) next = e.y;
         }
         cur = next;
+    }
+    __device__ __forceinline__ bool at_leaf() const { return cur != kRefNone && (cur & kRefLeaf) != 0u; }
+    __device__ __forceinline__ bool at_node() const { return (cur & kRefLeaf) == 0u; } // kRefNone has the leaf bit set
+
+    // cur names a primitive: the 48 bytes of its record (read no further: a primitive record read as 64 bytes would
+    // reach into the next cache line more often).  Measured and rejected: primitive records at a 64-byte stride,
+    // which never straddle a line but pack fewer neighbouring leaves into one (10 M soup 0.44 -> 0.40 Grays/s), and
+    // a left leaf's triangle carried in its parent's record (saves the fetch, but the extra triangle test in the
+    // node step costs more issue slots than the fetch: 0.452 -> 0.436).
+    __device__ __forceinline__ void step_leaf(const float4 *__restrict__ prims) {
+        const uint32_t index = cur & kRefIndex;
+        const float4 *__restrict__ p = prims + 3 * (size_t)index;
+        const float4 a = p[0], b = p[1], c = p[2];
+        if (cur & kRefSphere)
+            sphere_test(a, index, o, d, tmin, best);
+        else
+            tri_test(a, b, c, index, o, d, tmin, best);
+        advance(kRefNone);
+    }
+
+    // cur names an interior node: the 128 bytes of its record
+    __device__ __forceinline__ void step_node(const float4 *__restrict__ chain) {
+        const float4 *__restrict__ p = chain + 8 * (size_t)cur;
+        const float4 a = p[0], b = p[1], c = p[2], q = p[3], n1 = p[4], nz = p[5], n2 = p[6], refs = p[7];
+        uint32_t next = kRefNone;
+        const uint32_t meta = f2u(q.z);
+        const uint32_t levels = meta >> 16;
+        float el, xl, er, xr;
+        slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, el, xl);
+        slab_pair(c.x, c.y, c.z, c.w, b.z, b.w, o, inv, tmin, er, xr);
+        bool hit_l = !(min_raw(best.t, xl) <= el);
+        bool hit_r = !(min_raw(best.t, xr) <= er);
+        if (hit_r && hit_l) stack.push(er, f2u(q.y));
+        if (!hit_l) {
+            if (hit_r) next = f2u(q.y);
+        } else if (levels < 2u) {
+            next = f2u(q.x);
+        } else { // L's children, from L's box
+            float box[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+            const float fresh1[6] = {n1.x, n1.y, n1.z, n1.w, nz.x, nz.y};
+            pair_below(box, fresh1, meta, hit_l, hit_r, er);
+            if (hit_r && hit_l) stack.push(er, f2u(refs.y));
+            if (!hit_l) {
+                if (hit_r) next = f2u(refs.y);
+            } else if (levels < 3u) {
+                next = f2u(refs.x);
+            } else { // LL's children, from LL's box
+                const float fresh2[6] = {n2.x, n2.y, n2.z, n2.w, nz.z, nz.w};
+                pair_below(box, fresh2, meta >> 8, hit_l, hit_r, er);
+                if (hit_r && hit_l) stack.push(er, f2u(refs.w));
+                if (hit_l)
+                    next = f2u(refs.z);
+                else if (hit_r)
+                    next = f2u(refs.w);
+            }
+        }
+        advance(next);
+    }
+
+    // One step whatever cur names (lanes of a wave in lockstep: one memory round per step).
+    __device__ __forceinline__ void step(const float4 *__restrict__ chain, const float4 *__restrict__ prims) {
+        if (cur & kRefLeaf)
+            step_leaf(prims);
+        else
+            step_node(chain);
     }
 };
 
@@ -1273,7 +1295,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                 continue;
             }
         }
-        if (have && walk.cur != kRefNone) walk.step(chain, prims);
+        // Lanes whose next step is a primitive test wait until they are a quarter of the walking lanes (or nothing
+        // else is left): a wave then runs the node code or the triangle code in a round, not both in every round.
+        const bool leaf_lane = have && walk.at_leaf(), node_lane = have && walk.at_node();
+        const uint32_t n_leaf = __popcll(__ballot(leaf_lane)), n_node = __popcll(__ballot(node_lane));
+        if (n_node == 0u || n_leaf * RT_LEAF_DIV >= n_node + n_leaf) {
+            if (leaf_lane) walk.step_leaf(prims);
+        } else {
+            if (node_lane) walk.step_node(chain);
+        }
     }
     for (int sh = 32; sh > 0; sh >>= 1) n_rays += __shfl_down(n_rays, sh);
     if (lane == 0u && n_rays) atomicAdd(&s_rays, n_rays);
