@@ -94,8 +94,10 @@ struct rt_context {
     uint64_t max_paths = 1ull << 26;
     uint32_t timed_bounces = 0xFFFFFFFFu;
     uint32_t pipeline = RT_PIPELINE_AUTO;
-    bool lanes_lockstep_first = false; // LANES: camera rays by the per-bounce kernel first (environment variable RT_LANES_FIRST=lockstep)
-    int lanes_waves = 4;              // waves per SIMD the LANES kernel's registers are budgeted for (RT_LANES_WAVES)              // waves per SIMD of the LANES kernel (environment variable RT_LANES_WAVES)
+    // LANES knobs, 0 = chosen per scene (environment variables RT_LANES_TRAVERSAL, RT_LANES_FIRST, RT_LANES_WAVES)
+    int lanes_traversal = 0; // +1 chain records, -1 stackless walk
+    int lanes_first = 0;     // +1 bounce 0 by the per-bounce kernel in lockstep, -1 lanes from the camera ray on
+    int lanes_waves = 0;     // waves per SIMD the kernel's registers are budgeted for
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
     // wavefront workspace
@@ -258,7 +260,9 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
         long v = std::strtol(e, nullptr, 10);
         if (v >= 1 && v <= 64) c->blocks_per_cu = (uint32_t)v;
     }
-    if (const char *e = std::getenv("RT_LANES_FIRST")) c->lanes_lockstep_first = std::strcmp(e, "lockstep") == 0;
+    if (const char *e = std::getenv("RT_LANES_TRAVERSAL"))
+        c->lanes_traversal = !std::strcmp(e, "chain") ? 1 : !std::strcmp(e, "walk") ? -1 : 0;
+    if (const char *e = std::getenv("RT_LANES_FIRST")) c->lanes_first = !std::strcmp(e, "lockstep") ? 1 : !std::strcmp(e, "lanes") ? -1 : 0;
     if (const char *e = std::getenv("RT_LANES_WAVES")) {
         long v = std::strtol(e, nullptr, 10);
         if (v >= 4 && v <= 8 && v != 7) c->lanes_waves = (int)v;
@@ -671,21 +675,24 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     uint32_t pipeline = c->pipeline;
     // AUTO: tables up to 40 KB go to LDS once per 256-thread block; up to 150 KB once per 1024-thread block, one
     // block per CU (485 spheres, 54 KB: 12.4 vs 8.8 Grays/s from L1/L2); larger scenes are read through the caches.
-    // Tables far beyond what the L2s hold (32 MiB in all) are read from HBM, where the number of cache lines fetched
-    // per ray is what counts: one lane per path over the 128-byte records (10 M triangles 0.44 vs 0.37 Grays/s, 1 M
-    // 0.81 vs 0.74; a cache-resident 100 k soup 2.3 vs 3.8, the teapot 3.7 vs 4.9: those stay with PATHS).
-    if (pipeline == RT_PIPELINE_AUTO)
-        pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS
-                   : (table_bytes > (64u << 20) && s->dev.chain) ? RT_PIPELINE_LANES
-                                                                 : RT_PIPELINE_PATHS;
+    // Larger tables: one lane per path (LANES).  Beyond what the L2s hold (32 MiB in all; the crossover is near
+    // 48 MB) the tables are read from HBM, where the number of cache lines fetched per ray is what counts: lanes walk
+    // the 128-byte chain records from the camera ray on (10 M triangles 0.53 vs 0.37 Grays/s for PATHS, 1 M 0.97 vs
+    // 0.74, 600 k 1.09 vs 0.97).  Below that the stackless walk over the 32-byte nodes costs fewer instructions; there
+    // bounce 0 runs in lockstep first (neighbouring pixels share their nodes) and lanes take over the survivors
+    // (teapot 5.3 vs 4.9 lit and 3.2 vs 2.5 with the default camera, 300 k soup 1.60 vs 1.46; small soups lose a
+    // little: 100 k 3.5 vs 3.75, 30 k 7.4 vs 7.5).
+    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_LANES;
     bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
                pipeline == RT_PIPELINE_PATHS_LDS;
     if (count) {
         if (c->pipeline == RT_PIPELINE_AUTO && table_bytes > 64u * 1024u) lds = false;
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     }
-    if (pipeline == RT_PIPELINE_LANES && !s->dev.chain) pipeline = RT_PIPELINE_PATHS;
     const bool lanes = pipeline == RT_PIPELINE_LANES;
+    const bool lanes_chain = lanes && s->dev.chain && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (48u << 20)));
+    const bool lanes_lockstep_first = c->lanes_first ? c->lanes_first > 0 : !lanes_chain;
+    const int lanes_waves = s->has_mix ? 4 : c->lanes_waves ? c->lanes_waves : (lanes_chain ? 4 : 6);
     if (s->has_mix && pipeline != RT_PIPELINE_PATHS && pipeline != RT_PIPELINE_PATHS_LDS && !lanes)
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     const bool big_blocks = pipeline == RT_PIPELINE_PATHS_LDS && table_bytes > 40u * 1024u;
@@ -697,7 +704,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;
     // Traversal of the PATHS kernels: the stack traversal over 64-byte records, or the stackless walk over the
     // 32-byte node table.
-    const bool stack = lanes;
+    const bool stack = lanes_chain;
     const uint32_t lds_bytes = lds ? (uint32_t)table_bytes : 0u;
     // One grid for every bounce of a batch: block b owns segment b of both queues (see QueueView).
     const uint32_t chunks = (uint32_t)((slots + 255) / 256);
@@ -709,7 +716,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // of that latency than six; 10 M soup 0.286 -> 0.325 Grays/s, while the L2-resident teapot loses 2 % with them.
     const bool eight_waves = pipeline == RT_PIPELINE_PATHS && table_bytes > (16u << 20);
     const uint32_t blocks_per_cu = c->blocks_per_cu ? c->blocks_per_cu
-                                   : lanes         ? 4u // one resident round; more walks in flight thrash the L2s
+                                   : lanes         ? (uint32_t)lanes_waves // one resident round; more chain walks in flight thrash the L2s
                                    : big_blocks    ? 1u
                                    : eight_waves   ? 8u
                                                    : (table_bytes <= 256u * 1024u ? 24u : 6u);
@@ -717,7 +724,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
     if (int rc = ensure_render(c, lanes ? 0 : slots, lanes ? 0 : (size_t)grid * cap, st->max_depth, grid)) return rc;
     if (int rc = c->radiance.ensure(slots)) return rc;
-    if (lanes && c->lanes_lockstep_first) { // survivors of bounce 0 pass through device memory once
+    if (lanes && lanes_lockstep_first) { // survivors of bounce 0 pass through device memory once
         if (int rc = c->ray_o.ensure(slots)) return rc;
         if (int rc = c->ray_d.ensure(slots)) return rc;
         if (int rc = c->beta.ensure(slots)) return rc;
@@ -777,7 +784,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             if (lanes)
                 rt::launch_paths_lanes(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->counts.ptr, c->early.ptr, s->need_uv,
-                                       s->has_mix, c->lanes_waves, spill, c->lanes_lockstep_first);
+                                       s->has_mix, lanes_waves, spill, lanes_lockstep_first, lanes_chain);
             else
                 rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr,
                                  c->early.ptr, s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves);

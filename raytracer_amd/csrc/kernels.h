@@ -52,7 +52,9 @@ constexpr int kStackEntriesInLds = RT_STACK_K;
 // arrays are not touched.  `counts` / `early` are the [max_depth + 1][grid] tables, rows 1.. zeroed by the caller.
 void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
                         uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *counts, uint32_t *early, bool need_uv, bool has_mix,
-                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep);
+                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep, bool chain);
+// `chain`: traverse the chain records with the per-lane stack; otherwise the stackless walk over the node table
+// (always from the camera ray on).
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals);
 

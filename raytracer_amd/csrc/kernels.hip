@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "kernels.h"
 #include "rt_math.h"
@@ -377,6 +378,48 @@ struct StackWalk {
             step_leaf(prims);
         else
             step_node(chain);
+    }
+};
+
+// The stackless pre-order walk (traverse() above) in the same begin / step form, for one lane per path over tables
+// that sit in the caches: cur is the index of the node to test next, or kRefLeaf | slot when the node just tested
+// was a leaf whose box is hit and its primitive test is still due (then `resume` is the node to go on with).
+struct PreorderWalk {
+    V3 o, d, inv;
+    float tmin;
+    Closest best;
+    uint32_t cur, resume, end;
+
+    __device__ __forceinline__ void init(uint2 *, const StackSpill &) { cur = kRefNone; }
+    __device__ __forceinline__ void begin(float4, float4, uint32_t, V3 origin, V3 dir, float t_min, float t_max) {
+        o = origin;
+        d = dir;
+        inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+        best = Closest{t_max, kMissSlot, 0.0f, 0.0f};
+        tmin = in_vgpr(t_min);
+        cur = 0u; // the root's own box is node 0's
+    }
+    __device__ __forceinline__ bool at_leaf() const { return cur != kRefNone && (cur & kRefLeaf) != 0u; }
+    __device__ __forceinline__ bool at_node() const { return (cur & kRefLeaf) == 0u; }
+    __device__ __forceinline__ void step_leaf(const float4 *__restrict__ prims) {
+        const uint32_t slot = cur & kRefIndex;
+        if (cur & kRefSphere)
+            sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+        else
+            tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+        cur = resume < end ? resume : kRefNone;
+    }
+    __device__ __forceinline__ void step_node(const float4 *__restrict__ nodes) {
+        const float4 nlo = nodes[2 * (size_t)cur], nhi = nodes[2 * (size_t)cur + 1];
+        const bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+        const uint32_t leaf = f2u(nhi.w);
+        const uint32_t next = hit ? cur + 1u : f2u(nhi.z);
+        if (hit && leaf != kInterior) {
+            resume = next;
+            cur = kRefLeaf | ((leaf & kSphereBit) ? kRefSphere : 0u) | (leaf & ~kSphereBit);
+        } else {
+            cur = next < end ? next : kRefNone;
+        }
     }
 };
 
@@ -1198,13 +1241,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
 // bounce 0 has been traced by k_bounce (64 neighbouring pixels per wave in lockstep: their walks touch the same
 // nodes, which the vector cache then fetches once per wave) and lanes take the surviving paths from the block's
 // segment of `queue` (`pool[b]` entries), whose first rays the caller has counted already.
-template <bool NEED_UV, bool HAS_MIX, int WAVES, int K, bool FROM_CAMERA>
+// CHAIN: the stack traversal over the 128-byte chain records (scenes read from HBM); otherwise the stackless walk
+// over the 32-byte node table (scenes that sit in the L2s).
+template <bool NEED_UV, bool HAS_MIX, int WAVES, int K, bool FROM_CAMERA, bool CHAIN = true>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : WAVES))) void k_paths_lanes(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, const uint32_t *__restrict__ queue,
     const uint32_t *__restrict__ pool, uint32_t *__restrict__ ray_counts, StackSpill spill) {
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_next, s_rays;
-    const float4 *__restrict__ chain = reinterpret_cast<const float4 *>(sc.chain);
+    const float4 *__restrict__ chain = reinterpret_cast<const float4 *>(CHAIN ? static_cast<const void *>(sc.chain) : static_cast<const void *>(sc.nodes));
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
     if (threadIdx.x == 0) {
@@ -1222,8 +1267,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
         my_items = pool[blockIdx.x];
     }
 
-    StackWalk<K, kBlock> walk;
+    typename std::conditional<CHAIN, StackWalk<K, kBlock>, PreorderWalk>::type walk;
     walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
+    if constexpr (!CHAIN) walk.end = sc.n_nodes;
     Segment g{};
     uint32_t slot = 0, s_local = 0, pixel = 0, n_rays = 0;
 
@@ -1481,8 +1527,28 @@ void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
 
 void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
                         uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *counts, uint32_t *early, bool need_uv, bool has_mix,
-                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep) {
+                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep, bool chain) {
     constexpr int K = kStackEntriesInLds;
+    if (!chain) { // the stackless walk: no stack memory
+        using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, StackSpill);
+        Kernel kernel;
+        if (camera_rays_in_lockstep) {
+            const QueueView all{nullptr, nullptr, cap, n_slots};
+            auto first = has_mix ? k_bounce<true, false, true, true, 0> : need_uv ? k_bounce<true, false, true, false, 0> : k_bounce<true, false, false, false, 0>;
+            hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), 0, s, sc, P, st, all, queue, counts + grid, early + grid, spill);
+            if (P.max_depth < 2u) return;
+            kernel = has_mix      ? k_paths_lanes<true, true, 4, K, false, false>
+                     : waves >= 6 ? (need_uv ? k_paths_lanes<true, false, 6, K, false, false> : k_paths_lanes<false, false, 6, K, false, false>)
+                                  : (need_uv ? k_paths_lanes<true, false, 4, K, false, false> : k_paths_lanes<false, false, 4, K, false, false>);
+        } else {
+            kernel = has_mix      ? k_paths_lanes<true, true, 4, K, true, false>
+                     : waves >= 6 ? (need_uv ? k_paths_lanes<true, false, 6, K, true, false> : k_paths_lanes<false, false, 6, K, true, false>)
+                                  : (need_uv ? k_paths_lanes<true, false, 4, K, true, false> : k_paths_lanes<false, false, 4, K, true, false>);
+        }
+        uint32_t *ray_counts = counts + (size_t)(camera_rays_in_lockstep ? 2u : 1u) * grid;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue, counts + grid, ray_counts, spill);
+        return;
+    }
     const uint32_t stack_bytes = (uint32_t)(K * kBlock * sizeof(uint2));
     if (camera_rays_in_lockstep) { // bounce 0 by the per-bounce kernel: survivors into `queue`, rows 1 of the tables
         const QueueView all{nullptr, nullptr, cap, n_slots};
