@@ -286,6 +286,46 @@ def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
     ctx.close()
 
 
+@pytest.mark.parametrize("traversal", ["walk", "chain"])
+@pytest.mark.parametrize("first", ["lockstep", "lanes"])
+def test_lanes_pipeline_variants(cornell, teapot, monkeypatch, traversal, first):
+    """The one-lane-per-path pipeline with either traversal (stackless walk over the 32-byte nodes, per-lane stack
+    over the 128-byte chain records) and either way of tracing bounce 0 (per-bounce kernel in lockstep first, or
+    lanes from the camera ray on), whatever AUTO would pick for the scene: sums and ray counts equal the oracle's.
+    Scenes: every material kind, spheres with defocus, a mesh deep enough for the stack to spill out of LDS, a
+    Mix scene, and the degenerate trees of one and two primitives (the root is a leaf / the only record)."""
+    monkeypatch.setenv("RT_LANES_TRAVERSAL", traversal)
+    monkeypatch.setenv("RT_LANES_FIRST", first)
+    ctx = Context(0)
+    ctx.set_pipeline(F.RT_PIPELINE_LANES)
+    sph, sph_cam = rtiow_final_scene()
+    lit, lit_cam = lit_teapot(teapot)
+    soup, soup_cam = triangle_soup(60000, emissive_fraction=0.02)
+    one = SceneDescription()
+    one.meshes.append(TriangleMesh(np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32),
+                                   np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), one.lambertian((0.5, 0.6, 0.7))))
+    two = SceneDescription(list(one.meshes), [Sphere((0.0, 0.0, -1.0), 0.5, 0)], list(one.materials), list(one.textures))
+    from raytracer_amd.scene import CameraSettings
+
+    tiny_cam = CameraSettings.look_at((0.0, 0.0, 3.0), (0.0, 0.0, 0.0), 50.0, z_near=1e-3)
+    cases = [(cornell_with(cornell), None, RenderSettings(120, 90, 0, 50, 6, (0.2, 0.1, 0.3), F.RT_MODE_LINEAR_MEAN, 3)),
+             (cornell, None, RenderSettings(31, 17, 0, 1, 3, mode=F.RT_MODE_LINEAR_MEAN, seed=5)),
+             (cornell, None, RenderSettings(64, 48, 0, 2, 3, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=6)),
+             (sph, sph_cam, RenderSettings(160, 90, 0, 50, 4, (0.7, 0.8, 1.0), F.RT_MODE_GAMMA_PER_SAMPLE, 6)),
+             (lit, lit_cam, RenderSettings(160, 100, 0, 50, 3, mode=F.RT_MODE_LINEAR_MEAN, seed=7)),
+             (soup, soup_cam, RenderSettings(128, 96, 0, 50, 3, mode=F.RT_MODE_LINEAR_MEAN, seed=4)),
+             (mix_scene(cornell, lambda sc: (sc.mix(sc.lambertian((0.7, 0.6, 0.5)), sc.metal((0.9, 0.85, 0.8), 0.3), 0.5),
+                                             sc.mix(sc.dielectric(1.5), sc.diffuse_light((1.0, 0.9, 0.8), 3.0), 0.35))), None,
+              RenderSettings(96, 64, 0, 50, 4, (0.05, 0.1, 0.2), F.RT_MODE_LINEAR_MEAN, 22)),
+             (one, tiny_cam, RenderSettings(48, 48, 0, 8, 4, (0.3, 0.4, 0.5), F.RT_MODE_LINEAR_MEAN, 2)),
+             (two, tiny_cam, RenderSettings(48, 48, 0, 8, 4, (0.3, 0.4, 0.5), F.RT_MODE_GAMMA_PER_SAMPLE, 2))]
+    for desc, cs, rs in cases:
+        gpu, cpu, gst, cst = render_pair(ctx, desc, cs or desc.camera(0), rs)
+        assert_images_equal(gpu, cpu)
+        assert gst.rays_traced == cst.rays_traced and gst.pipeline == F.RT_PIPELINE_LANES
+    ctx.close()
+
+
 def test_mid_size_scene_uses_the_shared_lds_copy(gpu_ctx):
     """Scene tables between 40 and 150 KB (here 1200 triangles = 134 KB, and the 485 spheres = 54 KB) are staged
     in LDS once per 1024-thread block by the default pipeline; sums and ray counts equal the oracle's."""

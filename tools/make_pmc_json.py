@@ -35,23 +35,30 @@ for f in glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), re
         k = row["Kernel_Name"]
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
         calls[k][row["Counter_Name"]] += 1
-render = [k for k in tot if "rt::k_paths" in k or "rt::k_bounce" in k or "rt::k_extend" in k]
-kernel = max(render, key=lambda k: tot[k].get("SQ_WAVE_CYCLES", 0.0))
-c = {name: tot[kernel][name] / calls[kernel][name] for name in tot[kernel]}
+# A launch of a leg is one or two render kernels (LANES with bounce 0 in lockstep first: k_bounce + k_paths_lanes):
+# their counters are added up and divided by the number of launches.
+render = sorted((k for k in tot if "rt::k_paths" in k or "rt::k_bounce" in k or "rt::k_extend" in k or "rt::k_shade" in k
+                 or "rt::k_generate" in k), key=lambda k: -tot[k].get("SQ_WAVE_CYCLES", 0.0))
+launches = meta["launches"]
+names = sorted({n for k in render for n in tot[k]})
+c = {name: sum(tot[k].get(name, 0.0) for k in render) / launches for name in names}
+kernel = " + ".join(k.split("(")[0] for k in render)
 rays = meta["rays_per_launch"]
 
 avg_ms = None
 stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], out_csv)
+    total_ns = 0.0
     for row in csv.DictReader(open(stats[0])):
-        if row["Name"].split("(")[0] == kernel.split("(")[0]:
-            avg_ms = float(row["AverageNs"]) * 1e-6
+        if any(row["Name"].split("(")[0] == k.split("(")[0] for k in render):
+            total_ns += float(row["TotalDurationNs"])
+    avg_ms = total_ns * 1e-6 / launches
 
 simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0  # the counter sums the 8 XCDs' busy cycles
 res = {
-    "leg": meta["profile_leg"], "workload": meta["workload"], "kernel": kernel.split("(")[0],
-    "dispatches_per_pass": calls[kernel]["SQ_WAVE_CYCLES"], "rays_per_dispatch": rays, "source_digest": meta["source_digest"],
+    "leg": meta["profile_leg"], "workload": meta["workload"], "kernel": kernel,
+    "launches_per_pass": launches, "rays_per_dispatch": rays, "source_digest": meta["source_digest"],
     "avg_dispatch_ms": avg_ms, "counters_per_dispatch": c,
     "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
     "valu_busy_share_of_simd_cycles": 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles,
@@ -64,7 +71,7 @@ res = {
         "hbm_read_requests": c.get("TCC_EA0_RDREQ_sum", 0.0) / rays,
         "l2_read_requests": c.get("TCP_TCC_READ_REQ_sum", 0.0) / rays,
     },
-    "note": "averages over the dispatches of the leg's render kernel in each pass; GRBM_GUI_ACTIVE is summed over the 8 "
+    "note": "per launch: counters of the leg's render kernels summed over a pass and divided by its launches; GRBM_GUI_ACTIVE is summed over the 8 "
             "XCDs; the busy share divides counters of different passes",
 }
 json.dump(res, open(out_json, "w"), indent=1)
