@@ -279,13 +279,14 @@ int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
  *   PATHS   one kernel launch per batch: every block generates its share of camera rays and then keeps
  *           bouncing its own survivors (a block only consumes the queue segment it produced, so no grid-wide
  *           synchronisation is needed between bounces)
- *   LANES   one kernel launch per batch with one lane per PATH: a lane keeps its path in registers from the
- *           camera ray to its end, is shaded where it is when its walk finishes and takes the next path of its
- *           block's share when the path ends; no queues and no path state in device memory.  For scenes read from
- *           HBM, where walks are chains of dependent fetches of very uneven length.
+ *   LANES   one lane per PATH: a lane keeps its path in registers until it ends, is shaded where it is when its
+ *           walk finishes and takes the next path of its block's share when the path ends; no queues.  Tables above
+ *           48 MB are read from HBM: the walk runs over 128-byte records holding up to three levels of child boxes
+ *           with a per-lane stack in LDS, from the camera ray on.  Smaller tables sit in the L2s: the stackless walk
+ *           over the 32-byte nodes, after bounce 0 has been traced with 64 neighbouring pixels per wave.
  *   AUTO    PATHS_LDS when the tables fit in 150 KB of LDS (256-thread blocks up to 40 KB, above that one
- *           1024-thread block per CU shares the copy), else PATHS: the fastest measured on every scene.  The other
- *           *_LDS pipelines take tables up to 64 KB. */
+ *           1024-thread block per CU shares the copy), else LANES: the fastest measured on the benchmark scenes.
+ *           The other *_LDS pipelines take tables up to 64 KB. */
 enum {
     RT_PIPELINE_AUTO = 0,
     RT_PIPELINE_SPLIT = 1,
