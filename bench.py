@@ -38,7 +38,13 @@ SPP_PER_STEP = 64
 MAX_PATHS = 1 << 27          # path slots per batch: the 64 samples of a 1080p frame a step renders
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; the chip's maximum shader clock
-VALU_PEAK = SIMDS * CLOCK_HZ / 4.0  # wave64 VALU instructions per second: one per SIMD every four cycles
+# wave64 VALU instructions per second: a SIMD is 32 lanes wide, so one instruction every two cycles (the chip's
+# 157.3 TFLOP/s of vector binary32 is this rate x 64 lanes x 2 flops of a fused multiply-add)
+VALU_PEAK = SIMDS * CLOCK_HZ / 2.0
+# What tools/calib/valu_issue.hip sustains on the chip with 6 waves per SIMD (profiles/r02_valu_issue.txt): streams of
+# independent add/mul/fma/mov/and/xor reach 0.70-0.80 of VALU_PEAK (the clock falls to 2.05-2.2 GHz under them);
+# min/max/compare/select/shift/integer multiply/convert/div_fixup issue once per 4.2 cycles, rcp/sqrt once per 8.2.
+VALU_SUSTAINED = {"full_rate_ops": 8.6e11, "half_rate_ops": 5.7e11, "quarter_rate_ops": 3.0e11}
 PIPELINES = {1: "split", 2: "fused", 3: "fused+lds", 4: "hybrid", 5: "hybrid+lds", 6: "split+lds", 7: "paths",
              8: "paths+lds", 9: "lanes"}
 
@@ -174,7 +180,7 @@ def run_leg(name, device, launches, warmup=1, width=None, height=None, want_coun
 
 def roofline_of(name, leg):
     """The roofline of a leg's render kernel.  Scenes whose tables live in LDS or the L2s are bound by VALU issue
-    (wave-level instructions per second against one per SIMD every four cycles); the soup is bound by HBM.  The
+    (wave-level instructions per second against one per SIMD every two cycles); the soup is bound by HBM.  The
     instruction and traffic counts come from the committed PMC profile of the same build and the same launch."""
     kernel_hint = {"lanes": "k_paths_lanes", "paths": "k_paths", "paths+lds": "k_paths"}.get(leg["pipeline"], "k_")
     prof, origin = committed_profile(name, kernel_hint, leg["rays_per_launch"])
@@ -201,7 +207,10 @@ def roofline_of(name, leg):
         ach = prof["per_ray"]["valu_wave_instructions"] * leg["rays_per_launch"] / secs
         r.update({"bound": "valu", "achieved": ach / 1e9, "peak": VALU_PEAK / 1e9, "unit": "G wave-instructions/s",
                   "frac": ach / VALU_PEAK, "traffic": traffic,
-                  "peak_is": f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz / 4 cycles per wave64 VALU instruction"})
+                  "peak_is": f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz / 2 cycles per wave64 VALU instruction "
+                             "(= 157.3 TFLOP/s of vector binary32)",
+                  "measured_issue_rates": {k: v / 1e9 for k, v in VALU_SUSTAINED.items()},
+                  "frac_of_measured_full_rate": ach / VALU_SUSTAINED["full_rate_ops"]})
     else:
         r.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave-instructions/s", "frac": None,
                   "traffic": None})
@@ -416,7 +425,9 @@ def main():
                      "box_tests_per_ray": ref["box_tests_per_ray"], "triangle_tests_per_ray": ref["triangle_tests_per_ray"],
                      "note": "Cornell's BVH and triangles (4 KB) are staged in LDS: the algorithmic bytes never leave the CU, "
                              "so the kernel is bound by VALU issue, not by HBM; frac = wave-level VALU instructions per "
-                             "second over the SIMDs' issue rate, algorithmic_gbs is the figure the byte formula gives"})
+                             "second over the SIMDs' peak issue rate (which only add/mul/fma-class instructions reach: "
+                             "the box test's compares, selects, min and max issue at half of it, see "
+                             "measured_issue_rates), algorithmic_gbs is the figure the byte formula gives"})
         out = {
             "metric": "Mrays/s per GPU and per node (1/2/4/8), Cornell 1080p; time to 1024 spp",
             "value": rays_all / elapsed / 1e6,
