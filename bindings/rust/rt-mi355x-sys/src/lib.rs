@@ -228,4 +228,6 @@ extern "C" {
     pub fn rt_gltf_scene(gltf: *const rt_gltf) -> *const rt_scene_desc;
     pub fn rt_gltf_camera_count(gltf: *const rt_gltf) -> u32;
     pub fn rt_gltf_camera(gltf: *const rt_gltf, index: u32, out: *mut rt_camera_settings) -> c_int;
+    pub fn rt_image_decode(bytes: *const c_void, size: usize, width: *mut u32, height: *mut u32, pixels: *mut *mut u8) -> c_int;
+    pub fn rt_image_free(pixels: *mut u8);
 }

@@ -394,10 +394,8 @@ int rt_render_node(rt_context *const *ctxs, const rt_scene *const *scenes, int n
  * way the reference's loader does — every node's LOCAL transform, the first TRIANGLES primitive of its mesh,
  * positions transformed and normals not, emissive materials as white DiffuseLight of the emissive strength and
  * everything else as Lambertian of the base colour factor, perspective cameras with focus distance 10.
- * Base-colour textures (`load_image`, src/scene.rs:87-114) are decoded from PNG: 8-bit grey, grey+alpha, RGB,
- * RGBA, palette and 1/2/4-bit grey, interlaced or not; 16-bit samples are refused as the reference refuses
- * them, and JPEG files are refused because no JPEG decoder is linked (both RT_ERR_PARSE).  The returned
- * object owns every buffer the scene description points into. */
+ * Base-colour textures (`load_image`, src/scene.rs:87-114) are decoded as `rt_image_decode` below decodes them.
+ * The returned object owns every buffer the scene description points into. */
 typedef struct rt_gltf rt_gltf;
 int rt_gltf_load(const char *path, rt_gltf **out);
 int rt_gltf_free(rt_gltf *gltf);
@@ -407,6 +405,21 @@ const rt_scene_desc *rt_gltf_scene(const rt_gltf *gltf);
  * file's cameras yields CameraSettings::default. */
 uint32_t rt_gltf_camera_count(const rt_gltf *gltf);
 int rt_gltf_camera(const rt_gltf *gltf, uint32_t index, rt_camera_settings *out);
+
+/* The texels of an image file held in memory as the reference's loader sees them (`gltf::import` decodes the file,
+ * `load_image`, src/scene.rs:87-114, wraps the result and `Image::value_at`, src/texture.rs:115-136, reads channels
+ * 0..2): `*pixels` receives 3 * width * height bytes, row-major RGB, top row first, (l, l, l) for grey images, alpha
+ * dropped; release them with `rt_image_free`.
+ *   PNG: 8-bit grey, grey+alpha, RGB, RGBA, palette and 1/2/4-bit grey, interlaced or not; 16-bit samples are refused
+ *        as the reference refuses them.  Lossless, so these are the reference's texels.
+ *   JPEG: baseline, extended-sequential and progressive Huffman files with 8-bit samples, grey or three components,
+ *        chroma subsampled by 1 or 2 per direction; CMYK, arithmetic coding, lossless and 12-bit files are refused.
+ *        The integer inverse DCT, the linear chroma upsampling and the integer YCbCr -> RGB conversion follow the
+ *        decoder the reference links (zune-jpeg 0.4.11) as far as its algorithms are known; no fixture of the
+ *        reference pins these texels.
+ * Anything refused or malformed yields RT_ERR_PARSE with the reason in rt_last_error(). */
+int rt_image_decode(const void *bytes, size_t size, uint32_t *width, uint32_t *height, uint8_t **pixels);
+void rt_image_free(uint8_t *pixels);
 
 #ifdef __cplusplus
 }

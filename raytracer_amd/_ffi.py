@@ -144,6 +144,9 @@ EXPORTS = {
     "rt_gltf_scene": (C.POINTER(rt_scene_desc), [_vp]),
     "rt_gltf_camera_count": (C.c_uint32, [_vp]),
     "rt_gltf_camera": (C.c_int, [_vp, C.c_uint32, C.POINTER(rt_camera_settings)]),
+    "rt_image_decode": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.POINTER(C.c_uint8))]),
+    "rt_image_free": (None, [C.POINTER(C.c_uint8)]),
     "rt_render_device": (C.c_int, [_vp, _vp, C.POINTER(rt_camera), C.POINTER(rt_settings), _vp,
                                    C.POINTER(rt_stats)]),
     "rt_allreduce_sum": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_size_t]),

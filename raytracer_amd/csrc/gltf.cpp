@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
+#include "jpeg_decode.h"
 #include "png_decode.h"
 
 namespace rt {
@@ -384,21 +385,25 @@ int add_solid(rt_gltf &g, float r, float gr, float b) {
     return (int)g.textures.size() - 1;
 }
 
-// `load_image` (src/scene.rs:87-114) on the image the gltf crate decoded: PNG only here (no JPEG decoder).
+// `load_image` (src/scene.rs:87-114) on the image the gltf crate decoded (PNG or JPEG, told apart by their signatures
+// as the crate's `guess_format` does): 8-bit RGB texels, (l, l, l) for grey images.
 struct DecodedImage {
     uint32_t width = 0, height = 0;
     std::vector<uint8_t> rgb;
 };
 
-DecodedImage decode_image(const std::string &file) {
-    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(file.data());
-    if (file.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8)
-        throw std::runtime_error("JPEG base-colour textures are not supported (no JPEG decoder in this build); use PNG");
+DecodedImage decode_image(const uint8_t *bytes, size_t size) {
     DecodedImage img;
     std::string err;
-    if (!rt::decode_png_rgb8(bytes, file.size(), img.width, img.height, img.rgb, err))
-        throw std::runtime_error("base-colour texture: " + err);
+    const bool jpeg = size >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8;
+    const bool ok = jpeg ? rt::decode_jpeg_rgb8(bytes, size, img.width, img.height, img.rgb, err)
+                         : rt::decode_png_rgb8(bytes, size, img.width, img.height, img.rgb, err);
+    if (!ok) throw std::runtime_error("base-colour texture: " + err);
     return img;
+}
+
+DecodedImage decode_image(const std::string &file) {
+    return decode_image(reinterpret_cast<const uint8_t *>(file.data()), file.size());
 }
 
 int add_image(rt_gltf &g, DecodedImage &&img) {
@@ -575,5 +580,32 @@ __attribute__((visibility("default"))) int rt_gltf_free(rt_gltf *g) {
     delete g;
     return RT_OK;
 }
+
+__attribute__((visibility("default"))) int rt_image_decode(const void *bytes, size_t size, uint32_t *width, uint32_t *height,
+                                                           uint8_t **pixels) {
+    if (!bytes || !width || !height || !pixels) {
+        rt::set_last_error("rt_image_decode: null argument");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    *pixels = nullptr;
+    try {
+        DecodedImage img = decode_image(static_cast<const uint8_t *>(bytes), size);
+        uint8_t *out = static_cast<uint8_t *>(malloc(img.rgb.empty() ? 1 : img.rgb.size()));
+        if (!out) throw std::bad_alloc();
+        memcpy(out, img.rgb.data(), img.rgb.size());
+        *width = img.width;
+        *height = img.height;
+        *pixels = out;
+    } catch (const std::bad_alloc &) {
+        rt::set_last_error("out of memory");
+        return RT_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        rt::set_last_error(e.what());
+        return RT_ERR_PARSE;
+    }
+    return RT_OK;
+}
+
+__attribute__((visibility("default"))) void rt_image_free(uint8_t *pixels) { free(pixels); }
 
 } // extern "C"

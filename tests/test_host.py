@@ -350,7 +350,7 @@ def test_png_base_colour_textures(tmp_path):
     """Base-colour textures (`load_image`, src/scene.rs:87-114; texel use in src/texture.rs:115-136): the
     library's PNG decoder and the Python reader's give the texels the PNG holds — (l, l, l) for grey, palette
     expanded, alpha dropped, sub-byte grey scaled to 0..255 — for every colour type, filter type, Adam7
-    interlacing and all three ways a glTF file can carry an image; 16-bit samples and JPEG files are refused.
+    interlacing and all three ways a glTF file can carry an image; 16-bit samples and damaged files are refused.
     Pillow, where importable, cross-checks the test's own PNG writer."""
     import io
 
@@ -416,6 +416,118 @@ def test_png_base_colour_textures(tmp_path):
     assert b"JPEG" in lib.rt_last_error()
     broken = cases[0][1][:-40]
     assert lib.rt_gltf_load(os.fsencode(_textured_gltf(tmp_path, "broken", broken, "uri")), C.byref(handle)) == F.RT_ERR_PARSE
+
+
+def test_jpeg_base_colour_textures(tmp_path):
+    """JPEG base-colour textures (`gltf::import` -> `load_image`, src/scene.rs:87-114, 138-149).  The reference holds no
+    JPEG fixture and its decoder (zune-jpeg 0.4.11) cannot run here, so the texels are parity-unpinned; what is
+    checked: (1) the stages the decoder states — exact inverse transform of flat blocks, the integer YCbCr -> RGB
+    formula, the 3:1 linear chroma upsampling with repeated edges — on files whose coefficients are known exactly;
+    (2) agreement with libjpeg-turbo (through Pillow) within a few code values for baseline and progressive files,
+    every chroma layout Pillow writes, restart intervals, odd sizes; (3) refusals; (4) the way through both glTF readers."""
+    import io
+
+    Image = pytest.importorskip("PIL.Image")
+    from raytracer_amd.scene import decode_image_rgb8, load_from_gltf, load_from_gltf_native
+
+    def jpeg(array, mode=None, **kw):
+        buf = io.BytesIO()
+        Image.fromarray(array, mode).save(buf, format="JPEG", **kw)
+        return buf.getvalue()
+
+    def clamp(x):
+        return np.clip(x, 0, 255)
+
+    def to_rgb(y, cb, cr):
+        y, cb, cr = y.astype(np.int64), cb.astype(np.int64) - 128, cr.astype(np.int64) - 128
+        return np.stack([clamp(y + ((45 * cr) >> 5)), clamp(y - ((11 * cb + 23 * cr) >> 5)), clamp(y + ((113 * cb) >> 6))], -1)
+
+    # (1a) flat grey blocks at quality 100 (all quantisers 1) hold DC = 8 * (v - 128) exactly: every level comes back
+    levels = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    flat = np.kron(levels, np.ones((8, 8), dtype=np.uint8))
+    got = decode_image_rgb8(jpeg(flat, quality=100))
+    assert got.shape == (128, 128, 3) and np.array_equal(got, np.repeat(flat[..., None], 3, 2))
+    # (1b) the colour formula on flat YCbCr blocks, 4:4:4
+    rng = np.random.default_rng(21)
+    ycc = rng.integers(0, 256, (6, 9, 3)).astype(np.uint8)
+    ycc_img = np.kron(ycc, np.ones((8, 8, 1), dtype=np.uint8))
+    got = decode_image_rgb8(jpeg(ycc_img, "YCbCr", quality=100, subsampling=0))
+    assert np.array_equal(got, to_rgb(ycc_img[..., 0], ycc_img[..., 1], ycc_img[..., 2]))
+    # (1c) chroma upsampling: chroma constant over 16x16 (4:2:0), 16x8 (4:2:2) regions is coded exactly as one flat
+    # 8x8 block per region; the decoder must interpolate that plane 3:1, vertically first, rounding after each step
+    def up_rows(p):
+        a = np.vstack([p[:1], p[:-1]]).astype(np.int64)
+        b = np.vstack([p[1:], p[-1:]]).astype(np.int64)
+        out = np.empty((2 * p.shape[0], p.shape[1]), dtype=np.int64)
+        out[0::2] = (3 * p + a + 2) >> 2
+        out[1::2] = (3 * p + b + 2) >> 2
+        return out
+
+    def up_cols(p):
+        out = up_rows(p.T).T.copy()
+        out[:, 0] = p[:, 0]
+        out[:, -1] = p[:, -1]
+        return out
+
+    for sub, (fy, fx) in ((2, (2, 2)), (1, (1, 2))):
+        coarse = rng.integers(0, 256, (4, 5, 3)).astype(np.uint8)
+        img = np.kron(coarse, np.ones((8 * fy, 8 * fx, 1), dtype=np.uint8))
+        got = decode_image_rgb8(jpeg(img, "YCbCr", quality=100, subsampling=sub))
+        planes = []
+        for c in (1, 2):
+            p = np.kron(coarse[..., c], np.ones((8, 8), dtype=np.uint8)).astype(np.int64)
+            if fy == 2:
+                p = up_rows(p)
+            planes.append(up_cols(p))
+        assert np.array_equal(got, to_rgb(img[..., 0], planes[0], planes[1])), sub
+
+    # (2) against libjpeg-turbo
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 9.0 + y / 17.0), 127 + 120 * np.cos(x / 5.0 - y / 11.0), (x * 3 + y * 2) % 256], -1)
+        return np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+
+    worst = 0
+    for (h, w) in ((64, 64), (37, 53), (1, 1), (17, 200)):
+        img = picture(h, w)
+        for sub in (0, 1, 2):
+            for progressive in (False, True):
+                for restart in (0, 3):
+                    data = jpeg(img, quality=85, subsampling=sub, progressive=progressive, restart_marker_blocks=restart)
+                    want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(np.int64)
+                    got = decode_image_rgb8(data).astype(np.int64)
+                    assert got.shape == want.shape
+                    d = np.abs(got - want)
+                    worst = max(worst, int(d.max()))
+                    assert d.max() <= 5 and d.mean() <= 0.9, (h, w, sub, progressive, restart, d.max(), d.mean())
+        data = jpeg(img[..., 0], quality=85)
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(np.int64)
+        assert np.abs(decode_image_rgb8(data).astype(np.int64) - want).max() <= 1  # transform only
+    assert worst >= 1  # the colour conversion is the approximate integer one, not libjpeg's
+
+    # (3) refusals and damaged files: an error, never a crash
+    with pytest.raises(ValueError, match="CMYK"):
+        decode_image_rgb8(jpeg(np.zeros((8, 8, 4), dtype=np.uint8), "CMYK"))
+    good = jpeg(picture(40, 40), quality=80, subsampling=2, progressive=True)
+    with pytest.raises(ValueError, match="JPEG"):
+        decode_image_rgb8(good[:20])
+    with pytest.raises(ValueError, match="arithmetic"):
+        decode_image_rgb8(good.replace(b"\xff\xc2", b"\xff\xca", 1))
+    for cut in range(2, len(good), 37):
+        try:
+            decode_image_rgb8(good[:cut])
+        except ValueError:
+            pass
+
+    # (4) through both glTF readers, in a GLB buffer view and as an external file
+    img = picture(24, 40)
+    data = jpeg(img, quality=90, subsampling=2)
+    want = decode_image_rgb8(data)
+    for how in ("glb", "file", "uri"):
+        path = _textured_gltf(tmp_path, f"jpeg_{how}", data, how)
+        for sc in (load_from_gltf_native(path), load_from_gltf(path)):
+            t = sc.textures[sc.materials[sc.meshes[0].material].texture]
+            assert t.kind == F.RT_TEX_IMAGE and np.array_equal(t.image, want)
 
 
 def test_rust_binding_declares_every_entry_point():
