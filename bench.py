@@ -210,7 +210,9 @@ def roofline_of(name, leg):
                   "peak_is": f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz / 2 cycles per wave64 VALU instruction "
                              "(= 157.3 TFLOP/s of vector binary32)",
                   "measured_issue_rates": {k: v / 1e9 for k, v in VALU_SUSTAINED.items()},
-                  "frac_of_measured_full_rate": ach / VALU_SUSTAINED["full_rate_ops"]})
+                  "frac_of_measured_full_rate": ach / VALU_SUSTAINED["full_rate_ops"],
+                  # the figure a four-cycle-per-instruction model (SIMD-16 parts; the profiler's VALUBusy) would give
+                  "frac_at_four_cycles_per_instruction": ach / (VALU_PEAK / 2.0)})
     else:
         r.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave-instructions/s", "frac": None,
                   "traffic": None})
