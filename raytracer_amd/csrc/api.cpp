@@ -677,11 +677,11 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // block per CU (485 spheres, 54 KB: 12.4 vs 8.8 Grays/s from L1/L2); larger scenes are read through the caches.
     // Larger tables: one lane per path (LANES).  Beyond what the L2s hold (32 MiB in all; the crossover is near
     // 48 MB) the tables are read from HBM, where the number of cache lines fetched per ray is what counts: lanes walk
-    // the 128-byte chain records from the camera ray on (10 M triangles 0.53 vs 0.37 Grays/s for PATHS, 1 M 0.97 vs
-    // 0.74, 600 k 1.09 vs 0.97).  Below that the stackless walk over the 32-byte nodes costs fewer instructions; there
+    // the 128-byte chain records from the camera ray on (10 M triangles 0.62 vs 0.37 Grays/s for PATHS, 1 M 1.03 vs
+    // 0.74, 600 k 1.12 vs 0.96).  Below that the stackless walk over the 32-byte nodes costs fewer instructions; there
     // bounce 0 runs in lockstep first (neighbouring pixels share their nodes) and lanes take over the survivors
-    // (teapot 5.3 vs 4.9 lit and 3.2 vs 2.5 with the default camera, 300 k soup 1.60 vs 1.46; small soups lose a
-    // little: 100 k 3.5 vs 3.75, 30 k 7.4 vs 7.5).
+    // (teapot 6.7 vs 4.9 lit and 3.7 vs 2.5 with the default camera, 300 k soup 1.66 vs 1.46; small soups lose a
+    // little: 100 k 3.6 vs 3.74, 30 k 7.25 vs 7.5).
     if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_LANES;
     bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
                pipeline == RT_PIPELINE_PATHS_LDS;
