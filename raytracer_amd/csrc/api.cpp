@@ -542,6 +542,8 @@ RT_API int rt_camera_from_settings(const rt_camera_settings *s, uint32_t width, 
 // closest hit
 // ------------------------------------------------------------------------------------------------------
 namespace {
+// Closest-hit queries on scenes whose tables exceed this take one lane per ray (measured against the lockstep kernel).
+constexpr uint64_t kTraceLanesBytes = 150u * 1024u;
 // LDS bytes the extend kernel of a closest-hit query stages the scene tables in (0: read them through the caches).
 uint32_t trace_lds_bytes(const rt_context *c, const rt_scene *s) {
     const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
@@ -575,8 +577,27 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     const rt::QueueView all{nullptr, nullptr, 0u, (uint32_t)n};
     const uint32_t grid = (uint32_t)std::min<uint64_t>(c->max_blocks, (n + 255) / 256);
     const uint32_t lds_bytes = trace_lds_bytes(c, s);
-    rt::launch_extend(c->stream, grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, all, t_min, t_max, use_bvh != 0,
-                      count ? c->counters.ptr : nullptr, lds_bytes);
+    // Scenes beyond LDS size: one lane per ray (k_extend_lanes; teapot 5.4 vs 4.0 Grays/s of random rays, 1 M soup 0.51
+    // vs 0.30), over the chain records from 6 MB of tables on (queries are incoherent, so the records pay earlier than
+    // in a render: 60 k soup 1.23 vs 1.17 for the walk, 100 k 1.04 vs 0.78, 30 k 1.49 vs 1.67), else over the node table.
+    // RT_LANES_TRAVERSAL forces one of the two for any scene.  The instrumented kernel and the scan of the object list
+    // keep the lockstep kernel.
+    const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
+    const bool lanes = use_bvh && !count && (c->lanes_traversal != 0 || table_bytes > kTraceLanesBytes);
+    if (lanes) {
+        const bool chain = s->dev.chain && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (6u << 20)));
+        const uint32_t lanes_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cus * (chain ? 4u : 6u), (n + 255) / 256);
+        rt::StackSpill spill{nullptr, lanes_grid * 256u};
+        if (chain) {
+            if (int rc = c->stack_spill.ensure((size_t)std::max(1u, s->dev.depth) * spill.stride)) return rc;
+            spill.spill = c->stack_spill.ptr;
+        }
+        rt::launch_extend_lanes(c->stream, lanes_grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, t_min, t_max,
+                                spill, chain);
+    } else {
+        rt::launch_extend(c->stream, grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, all, t_min, t_max, use_bvh != 0,
+                          count ? c->counters.ptr : nullptr, lds_bytes);
+    }
     if (int rc = timed_end(c)) return rc;
     rt::launch_finalize_hits(c->stream, c->max_blocks, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, d_out);
     HIP_TRY(hipGetLastError());

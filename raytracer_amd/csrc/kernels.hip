@@ -1371,6 +1371,76 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
     if (threadIdx.x == 0) ray_counts[blockIdx.x] = s_rays;
 }
 
+// Closest hits of a batch of rays, one lane per ray, in the loop of k_paths_lanes without the shading: for scenes
+// whose tables are read from HBM (CHAIN: stack traversal over the chain records) or through the L2s (stackless walk).
+// Ray i's hit goes to hits[i]; block b owns the 256-ray chunks b, b + gridDim.x, ...
+template <int K, bool CHAIN>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 4 : 6))) void k_extend_lanes(
+    SceneDev sc, const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d, float4 *__restrict__ hits, uint32_t n,
+    float tmin, float tmax, StackSpill spill) {
+    extern __shared__ float4 s_scene[];
+    __shared__ uint32_t s_next;
+    const float4 *__restrict__ chain = reinterpret_cast<const float4 *>(CHAIN ? static_cast<const void *>(sc.chain) : static_cast<const void *>(sc.nodes));
+    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
+    const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunks = (n + kBlock - 1) / kBlock;
+    const uint32_t pool = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
+
+    typename std::conditional<CHAIN, StackWalk<K, kBlock>, PreorderWalk>::type walk;
+    walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
+    if constexpr (!CHAIN) walk.end = sc.n_nodes;
+    uint32_t slot = 0;
+    bool have = false, exhausted = false;
+    walk.cur = kRefNone;
+    for (;;) {
+        const bool finished = have && walk.cur == kRefNone;
+        const uint32_t n_fin = __popcll(__ballot(finished));
+        const uint32_t n_empty = __popcll(__ballot(!have));
+        const uint32_t n_busy = 64u - n_fin - n_empty;
+        const uint32_t idle = n_fin + (exhausted ? 0u : n_empty);
+        const uint32_t usable = 64u - (exhausted ? n_empty : 0u);
+        if (n_busy == 0u || idle * RT_SERVICE_DIV >= usable) {
+            if (finished) {
+                hits[slot] = make_float4(walk.best.t, u2f(walk.best.slot), walk.best.u, walk.best.v);
+                have = false;
+            }
+            const unsigned long long empty_mask = __ballot(!have);
+            if (!exhausted && empty_mask) {
+                const uint32_t want = __popcll(empty_mask);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_next, want);
+                base = __shfl(base, 0);
+                if (base + want >= pool) exhausted = true;
+                if (!have) {
+                    const uint32_t item = base + __popcll(empty_mask & ((1ull << lane) - 1ull));
+                    slot = ((item / kBlock) * gridDim.x + blockIdx.x) * kBlock + (item % kBlock);
+                    if (item < pool && slot < n) {
+                        walk.begin(root_lo, root_hi, sc.root_ref, xyz(ray_o[slot]), xyz(ray_d[slot]), tmin, tmax);
+                        have = true;
+                    }
+                }
+            }
+            if (__ballot(have) == 0ull) {
+                if (exhausted) break;
+                continue;
+            }
+        }
+#pragma nounroll
+        for (int r = 0; r < (CHAIN ? RT_ROUNDS_CHAIN : RT_ROUNDS_WALK); ++r) {
+            const bool leaf_lane = have && walk.at_leaf(), node_lane = have && walk.at_node();
+            const uint32_t n_leaf = __popcll(__ballot(leaf_lane)), n_node = __popcll(__ballot(node_lane));
+            if (n_node == 0u || n_leaf * RT_LEAF_DIV >= n_node + n_leaf) {
+                if (leaf_lane) walk.step_leaf(prims);
+            } else {
+                if (node_lane) walk.step_node(chain);
+            }
+        }
+    }
+}
+
 // Per-bounce ray totals of a batch: totals[it] = sum over blocks of counts[it][b] + early[it][b] (queued rays
 // plus rays whose miss was settled a bounce early).
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ counts,
@@ -1460,6 +1530,16 @@ static inline uint32_t grid_for(uint64_t items, uint32_t max_blocks) {
 
 void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, const PathState &st, uint32_t n_slots) {
     hipLaunchKernelGGL(k_generate, dim3(grid_for(n_slots, max_blocks)), dim3(kBlock), 0, s, P, st, n_slots);
+}
+
+void launch_extend_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d, float4 *hits,
+                         uint32_t n, float tmin, float tmax, const StackSpill &spill, bool chain) {
+    constexpr int K = kStackEntriesInLds;
+    if (chain)
+        hipLaunchKernelGGL((k_extend_lanes<K, true>), dim3(grid), dim3(kBlock), (uint32_t)(K * kBlock * sizeof(uint2)), s, sc, ray_o,
+                           ray_d, hits, n, tmin, tmax, spill);
+    else
+        hipLaunchKernelGGL((k_extend_lanes<K, false>), dim3(grid), dim3(kBlock), 0, s, sc, ray_o, ray_d, hits, n, tmin, tmax, spill);
 }
 
 void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,

@@ -287,6 +287,34 @@ def test_every_pipeline_matches_the_oracle(cornell, teapot, pipeline):
 
 
 @pytest.mark.parametrize("traversal", ["walk", "chain"])
+def test_closest_hit_queries_one_lane_per_ray(cornell, teapot, monkeypatch, traversal):
+    """rt_trace_closest on scenes beyond LDS size runs one lane per ray (k_extend_lanes), over the node table or over
+    the chain records depending on the scene's size; here either traversal is forced for every scene, including
+    LDS-sized ones, the degenerate trees of one and two primitives, and ray counts that leave waves part-filled:
+    hits equal the oracle's bit for bit."""
+    monkeypatch.setenv("RT_LANES_TRAVERSAL", traversal)
+    ctx = Context(0)
+    sph, _ = rtiow_final_scene()
+    soup, _ = triangle_soup(60000)
+    one = SceneDescription()
+    one.meshes.append(TriangleMesh(np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32),
+                                   np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), one.lambertian((0.5, 0.6, 0.7))))
+    two = SceneDescription(list(one.meshes), [Sphere((0.0, 0.0, -1.0), 0.5, 0)], list(one.materials), list(one.textures))
+    cases = [(cornell, (-1, -1, -1), (1, 1, 1), 70001), (teapot, (-35, -20, -22), (35, 18, 22), 50000),
+             (sph, (-12, 0, -12), (12, 3, 12), 30000), (soup, (-1, -1, -1), (1, 1, 1), 100000),
+             (one, (-1, -1, -2), (1, 1, 2), 1), (one, (-1, -1, -2), (1, 1, 2), 77), (two, (-1, -1, -2), (1, 1, 2), 4099)]
+    for k, (desc, lo, hi, n) in enumerate(cases):
+        g, o = both(ctx, desc)
+        rays = random_rays(n, lo, hi, seed=40 + k, axis_aligned_fraction=0.25)
+        rays["origin"][: n // 50, 2] = np.float32(lo[2])
+        for t_min, t_max in ((1e-4, np.inf), (0.05, 1.5)):
+            got, _ = g.trace_closest(rays, t_min, t_max)
+            want, _ = o.trace_closest(rays, t_min, t_max)
+            assert_hits_equal(got, want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("traversal", ["walk", "chain"])
 @pytest.mark.parametrize("first", ["lockstep", "lanes"])
 def test_lanes_pipeline_variants(cornell, teapot, monkeypatch, traversal, first):
     """The one-lane-per-path pipeline with either traversal (stackless walk over the 32-byte nodes, per-lane stack
