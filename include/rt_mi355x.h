@@ -337,8 +337,9 @@ int rt_trace_closest_device(rt_context *ctx, const rt_scene *scene, const rt_ray
 
 /* rt_trace_closest_device without any allocation.  No counterpart in the reference: it exists for callers that
  * cannot allocate device memory while they run — code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc.  Same kernels and same results as rt_trace_closest_device (no statistics); the ray and hit
- * staging that call keeps in the context's workspace lives here in a fixed array in device memory that the library
+ * forbid hipMalloc.  Same results as rt_trace_closest_device (no statistics), always by the lockstep closest-hit kernel
+ * (for large scenes rt_trace_closest_device runs one lane per ray over a stack whose spill area it sizes to the tree,
+ * an allocation); the ray and hit staging that call keeps in the context's workspace lives here in a fixed array in device memory that the library
  * holds on every GPU it runs on until the process ends (RT_NOALLOC_MAX_RAYS x 48 bytes = 3 MiB), whose address
  * was resolved when the context was created.  The call allocates and frees nothing, on the host or the device;
  * `n` > RT_NOALLOC_MAX_RAYS is refused with RT_ERR_INVALID_ARGUMENT.  Asynchronous on the context's stream.  All
