@@ -1,5 +1,5 @@
 #!/bin/bash
-# variant libraries in variants/ against the built one on the LANES legs
+# Variant builds of the library (variants/librt_<name>.so, names in $VARIANTS) against the built one on the LANES legs (run on the GPU box).
 out=gpurun_out/rr6; mkdir -p $out
 for v in base $VARIANTS; do
   lib=""; [ $v != base ] && lib="$PWD/variants/librt_$v.so"
