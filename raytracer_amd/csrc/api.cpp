@@ -589,7 +589,7 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
         const uint32_t lanes_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cus * (chain ? 4u : 6u), (n + 255) / 256);
         rt::StackSpill spill{nullptr, lanes_grid * 256u};
         if (chain) {
-            if (int rc = c->stack_spill.ensure((size_t)std::max(1u, s->dev.depth) * spill.stride)) return rc;
+            if (int rc = c->stack_spill.ensure((size_t)(2u * s->dev.depth + 2u) * spill.stride)) return rc;
             spill.spill = c->stack_spill.ptr;
         }
         rt::launch_extend_lanes(c->stream, lanes_grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, t_min, t_max,
@@ -698,8 +698,8 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // block per CU (485 spheres, 54 KB: 12.4 vs 8.8 Grays/s from L1/L2); larger scenes are read through the caches.
     // Larger tables: one lane per path (LANES).  Beyond what the L2s hold (32 MiB in all; the crossover is near
     // 48 MB) the tables are read from HBM, where the number of cache lines fetched per ray is what counts: lanes walk
-    // the 128-byte chain records from the camera ray on (10 M triangles 0.62 vs 0.37 Grays/s for PATHS, 1 M 1.03 vs
-    // 0.74, 600 k 1.12 vs 0.96).  Below that the stackless walk over the 32-byte nodes costs fewer instructions; there
+    // the 128-byte chain records from the camera ray on (10 M triangles 0.64 vs 0.37 Grays/s for PATHS, 1 M 1.15 vs
+    // 0.74, 600 k 1.30 vs 0.96).  Below that the stackless walk over the 32-byte nodes costs fewer instructions; there
     // bounce 0 runs in lockstep first (neighbouring pixels share their nodes) and lanes take over the survivors
     // (teapot 6.7 vs 4.9 lit and 3.7 vs 2.5 with the default camera, 300 k soup 1.66 vs 1.46; small soups lose a
     // little: 100 k 3.6 vs 3.74, 30 k 7.25 vs 7.5).
@@ -754,7 +754,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const uint32_t block_threads = big_blocks ? 1024u : 256u;
     rt::StackSpill spill{nullptr, grid * block_threads};
     if (stack) {
-        if (int rc = c->stack_spill.ensure((size_t)std::max(1u, s->dev.depth) * spill.stride)) return rc;
+        if (int rc = c->stack_spill.ensure((size_t)(2u * s->dev.depth + 2u) * spill.stride)) return rc;
         spill.spill = c->stack_spill.ptr;
     }
     const uint32_t n_batches = (total + B - 1) / B;

@@ -296,33 +296,31 @@ __global__ __launch_bounds__(kThreads) void k_chain(const Node *__restrict__ nod
         w.rx[0] = b.xlo, w.rx[1] = b.xhi, w.ry[0] = b.ylo, w.ry[1] = b.yhi, w.rz[0] = b.zlo, w.rz[1] = b.zhi;
         w.left = child_ref(nodes, l);
         w.right = child_ref(nodes, r);
-        uint32_t levels = 1u, mask1 = 0u, mask2 = 0u;
+        uint32_t below = 0u, mask1 = 0u, mask2 = 0u;
+        float parent[6], fresh[6];
         if (a.leaf == kInterior) { // the children of L, told from L's box
             const uint32_t ll = l + 1, lr = nodes[ll].skip;
-            const Node c = nodes[ll], d = nodes[lr];
-            float parent[6], fresh[6];
             planes_of(a, parent);
-            if (encode_pair(parent, c, d, fresh, mask1)) {
-                levels = 2u;
+            if (encode_pair(parent, nodes[ll], nodes[lr], fresh, mask1)) {
+                below |= 1u;
                 w.n1xy[0] = fresh[0], w.n1xy[1] = fresh[1], w.n1xy[2] = fresh[2], w.n1xy[3] = fresh[3];
                 w.n1z[0] = fresh[4], w.n1z[1] = fresh[5];
                 w.ll = child_ref(nodes, ll);
                 w.lr = child_ref(nodes, lr);
-                if (c.leaf == kInterior) { // the children of LL, told from LL's box
-                    const uint32_t lll = ll + 1, llr = nodes[lll].skip;
-                    const Node e = nodes[lll], f = nodes[llr];
-                    planes_of(c, parent);
-                    if (encode_pair(parent, e, f, fresh, mask2)) {
-                        levels = 3u;
-                        w.n2xy[0] = fresh[0], w.n2xy[1] = fresh[1], w.n2xy[2] = fresh[2], w.n2xy[3] = fresh[3];
-                        w.n2z[0] = fresh[4], w.n2z[1] = fresh[5];
-                        w.lll = child_ref(nodes, lll);
-                        w.llr = child_ref(nodes, llr);
-                    }
-                }
             }
         }
-        w.meta = mask1 | (mask2 << 8) | (levels << 16);
+        if (b.leaf == kInterior) { // the children of R, told from R's box
+            const uint32_t rl = r + 1, rr = nodes[rl].skip;
+            planes_of(b, parent);
+            if (encode_pair(parent, nodes[rl], nodes[rr], fresh, mask2)) {
+                below |= 2u;
+                w.n2xy[0] = fresh[0], w.n2xy[1] = fresh[1], w.n2xy[2] = fresh[2], w.n2xy[3] = fresh[3];
+                w.n2z[0] = fresh[4], w.n2z[1] = fresh[5];
+                w.rl = child_ref(nodes, rl);
+                w.rr = child_ref(nodes, rr);
+            }
+        }
+        w.meta = mask1 | (mask2 << 8) | (below << 16);
         chain[i - leaves_before(nodes, i)] = w;
     }
 }

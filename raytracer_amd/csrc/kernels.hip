@@ -207,7 +207,7 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
 // closest distance only shrinks, a right child that fails at push time would fail later too, and one that passed
 // (so X > E) passes later iff closest > E: the stack entry needs E only.  Visiting order, primitive tests and
 // every comparison are the reference's; what changes is that a node whose box is missed costs no memory access
-// and one 128-byte read serves up to three nodes of a left descent.
+// and one 128-byte read serves a node's children and grandchildren (step_node below).
 //
 // Why 128-byte records: a scattered read costs the memory system one 128-byte line whatever part of it is used
 // (measured: 5.4e10 reads/s of 32 bytes, 5.3e10 of 64, 5.0e10 of 128, 2.3e10 of 256 from a 2 GB table), and with a
@@ -215,8 +215,8 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
 // lines fetched per ray is what bounds a scene read from HBM.
 //
 // The stack: the K most recent entries live in LDS (entry e of a thread at lds[(e % K) * THREADS]), older ones
-// are moved to `spill` in device memory and come back when the LDS part runs empty.  At most depth - 1 entries
-// exist at a time.
+// are moved to `spill` in device memory and come back when the LDS part runs empty.  A step descends two levels and leaves at most three entries
+// behind, so fewer than 1.5 * depth + 2 entries exist at a time (the spill area has room for 2 * depth + 2).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void slab_pair(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, V3 o, V3 inv,
                                           float tmin, float &E, float &X) {
@@ -289,17 +289,18 @@ struct StackWalk {
     }
     // One pair of children of a node with planes `parent` (xlo, xhi, ylo, yhi, zlo, zhi): plane k of the left
     // child is the parent's when bit k of `mask` is set and `fresh[k]` otherwise, the right child takes the other.
-    // Decides both boxes; the left child's planes are left in `parent` for the next level.
-    __device__ __forceinline__ void pair_below(float parent[6], const float fresh[6], uint32_t mask, bool &hit_l, bool &hit_r, float &er) {
-        float right[6];
+    // Decides both boxes with the present closest distance; el, er are their entry distances.
+    __device__ __forceinline__ void pair_below(const float parent[6], const float fresh[6], uint32_t mask, bool &hit_l, bool &hit_r,
+                                               float &el, float &er) {
+        float left[6], right[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const bool inherit = (mask >> k) & 1u;
             right[k] = inherit ? fresh[k] : parent[k];
-            parent[k] = inherit ? parent[k] : fresh[k];
+            left[k] = inherit ? parent[k] : fresh[k];
         }
-        float el, xl, xr;
-        slab_pair(parent[0], parent[1], parent[2], parent[3], parent[4], parent[5], o, inv, tmin, el, xl);
+        float xl, xr;
+        slab_pair(left[0], left[1], left[2], left[3], left[4], left[5], o, inv, tmin, el, xl);
         slab_pair(right[0], right[1], right[2], right[3], right[4], right[5], o, inv, tmin, er, xr);
         hit_l = !(min_raw(best.t, xl) <= el);
         hit_r = !(min_raw(best.t, xr) <= er);
@@ -333,43 +334,57 @@ struct StackWalk {
         advance(kRefNone);
     }
 
-    // cur names an interior node: the 128 bytes of its record
+    // cur names an interior node X: the 128 bytes of its record decide X's children L, R and, where the record holds
+    // them, the children of those that pass.  BvhNode::hit would visit, in this order, LL's subtree, LR's, RL's, RR's
+    // (L's or R's own where the record does not hold their children): the first of them that passes is walked next,
+    // the others are pushed in reverse order.  L's children are decided for good now (nothing happens between L's
+    // test and theirs).  R's children wait on the stack while L's subtree is walked; BvhNode::hit tests R and then the
+    // child at that later moment, and since R passed now (so its exit lies beyond its entry) and the child's own
+    // exit-against-entry test is done now, what is left for later is "closest > R's entry and closest > the child's
+    // entry": the entry pushed with the child is the larger of the two.
     __device__ __forceinline__ void step_node(const float4 *__restrict__ chain) {
         const float4 *__restrict__ p = chain + 8 * (size_t)cur;
         const float4 a = p[0], b = p[1], c = p[2], q = p[3], n1 = p[4], nz = p[5], n2 = p[6], refs = p[7];
-        uint32_t next = kRefNone;
         const uint32_t meta = f2u(q.z);
-        const uint32_t levels = meta >> 16;
         float el, xl, er, xr;
         slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, el, xl);
         slab_pair(c.x, c.y, c.z, c.w, b.z, b.w, o, inv, tmin, er, xr);
-        bool hit_l = !(min_raw(best.t, xl) <= el);
-        bool hit_r = !(min_raw(best.t, xr) <= er);
-        if (hit_r && hit_l) stack.push(er, f2u(q.y));
-        if (!hit_l) {
-            if (hit_r) next = f2u(q.y);
-        } else if (levels < 2u) {
-            next = f2u(q.x);
-        } else { // L's children, from L's box
-            float box[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
-            const float fresh1[6] = {n1.x, n1.y, n1.z, n1.w, nz.x, nz.y};
-            pair_below(box, fresh1, meta, hit_l, hit_r, er);
-            if (hit_r && hit_l) stack.push(er, f2u(refs.y));
-            if (!hit_l) {
-                if (hit_r) next = f2u(refs.y);
-            } else if (levels < 3u) {
-                next = f2u(refs.x);
-            } else { // LL's children, from LL's box
-                const float fresh2[6] = {n2.x, n2.y, n2.z, n2.w, nz.z, nz.w};
-                pair_below(box, fresh2, meta >> 8, hit_l, hit_r, er);
-                if (hit_r && hit_l) stack.push(er, f2u(refs.w));
-                if (hit_l)
-                    next = f2u(refs.z);
-                else if (hit_r)
-                    next = f2u(refs.w);
+        const bool hit_l = !(min_raw(best.t, xl) <= el);
+        const bool hit_r = !(min_raw(best.t, xr) <= er);
+        uint32_t r0 = kRefNone, r1 = kRefNone, r2 = kRefNone, r3 = kRefNone; // in visiting order
+        float e1 = 0.0f, e2 = er, e3 = 0.0f;
+        if (hit_l) {
+            if (meta & (1u << 16)) {
+                const float box[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+                const float fresh[6] = {n1.x, n1.y, n1.z, n1.w, nz.x, nz.y};
+                bool h0, h1;
+                float e0;
+                pair_below(box, fresh, meta, h0, h1, e0, e1);
+                if (h0) r0 = f2u(refs.x);
+                if (h1) r1 = f2u(refs.y);
+            } else {
+                r0 = f2u(q.x);
             }
         }
-        advance(next);
+        if (hit_r) {
+            if (meta & (1u << 17)) {
+                const float box[6] = {c.x, c.y, c.z, c.w, b.z, b.w};
+                const float fresh[6] = {n2.x, n2.y, n2.z, n2.w, nz.z, nz.w};
+                bool h2, h3;
+                pair_below(box, fresh, meta >> 8, h2, h3, e2, e3);
+                e2 = max_raw(e2, er);
+                e3 = max_raw(e3, er);
+                if (h2) r2 = f2u(refs.z);
+                if (h3) r3 = f2u(refs.w);
+            } else {
+                r2 = f2u(q.y);
+            }
+        }
+        const bool any0 = r0 != kRefNone, any01 = any0 || r1 != kRefNone, any012 = any01 || r2 != kRefNone;
+        if (r3 != kRefNone && any012) stack.push(e3, r3);
+        if (r2 != kRefNone && any01) stack.push(e2, r2);
+        if (r1 != kRefNone && any0) stack.push(e1, r1);
+        advance(any0 ? r0 : r1 != kRefNone ? r1 : r2 != kRefNone ? r2 : r3);
     }
 
     // One step whatever cur names (lanes of a wave in lockstep: one memory round per step).
@@ -785,7 +800,7 @@ __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *l
 // ------------------------------------------------------------------------------------------------------
 // k_paths_lanes: rounds of walking between two service checks, per traversal
 #ifndef RT_ROUNDS_CHAIN
-#define RT_ROUNDS_CHAIN 64
+#define RT_ROUNDS_CHAIN 16
 #endif
 #ifndef RT_ROUNDS_WALK
 #define RT_ROUNDS_WALK 32
@@ -1351,7 +1366,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
         // Several rounds of walking between two looks at who has finished: the look (four ballots and the branches
         // around the service code) costs about as much as a box test, and lanes served in larger groups are shaded in
         // fuller waves.  Measured with 1 / 8 / 32 / 64 / 128 rounds: teapot 3.27 / 3.66 / 3.79 / 3.79 / 3.71 Grays/s (stackless
-        // walk), 10 M soup 0.53 / 0.58 / 0.60 / 0.60 / 0.59 (chain records; 256 rounds: 3.08 and 0.60).
+        // walk); chain records, 8 / 16 / 32 / 64 rounds: 10 M soup 0.614 / 0.623 / 0.624 / 0.614, 1 M soup 1.14 / 1.15 / 1.12 / 1.01.
         // In a round, lanes whose next step is a primitive test wait until they are a quarter of the walking lanes (or
         // nothing else is left): a wave then runs the node code or the triangle code in a round, not both.
 #pragma nounroll

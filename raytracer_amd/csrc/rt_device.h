@@ -33,18 +33,18 @@ static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 // The same tree once more for the stack traversal: one 128-byte record (one cache line: the unit every miss of
 // a scattered read costs, whatever part of it is used) per INTERIOR node X, indexed by X's rank among the interior
 // nodes in pre-order.  BvhNode::hit tests both children's boxes whenever it enters a node (src/bvh.rs:302-313), so
-// the record holds the boxes of X's children L and R in full, and, while they can be told, the boxes of the next
-// two levels down the left spine: the children of L and the children of L's left child LL.  A child box shares at
-// least one of each pair of opposite planes with its parent's box (a union's extreme is attained by one of its
-// parts), so a pair of children is stored as six "new" planes plus six bits saying which child inherits the
-// parent's plane and which takes the new one; the boxes come out bit for bit.  Where a pair does not have that
-// property (boxes padded differently, src/aabb.rs:78-93) the record simply stops a level earlier.  One fetch thus
-// serves up to three nodes of a left descent; right children are entered through their own records.
+// the record holds the boxes of X's children L and R in full, and, while they can be told, the boxes of all four
+// grandchildren: the children of L and the children of R.  A child box shares at least one of each pair of
+// opposite planes with its parent's box (a union's extreme is attained by one of its parts), so a pair of children
+// is stored as six "new" planes plus six bits saying which child inherits the parent's plane and which takes the
+// new one; the boxes come out bit for bit.  Where a pair does not have that property (boxes padded differently,
+// src/aabb.rs:78-93) the record does not hold it and the child is entered through its own record.  One fetch thus
+// serves two levels of the tree: a walk that starts at the root reads the records of every other level only.
 //   q0 = L.xlo, L.xhi, L.ylo, L.yhi     q1 = L.zlo, L.zhi, R.zlo, R.zhi     q2 = R.xlo, R.xhi, R.ylo, R.yhi
-//   q3 = ref L, ref R, meta, 0          meta: bits 0-5 inherit mask of (LL, LR), bits 8-13 of (LLL, LLR),
-//                                             bits 16-17 levels held (1, 2 or 3)
-//   q4 = new planes of (LL, LR): xlo, xhi, ylo, yhi       q5 = their zlo, zhi | zlo, zhi of (LLL, LLR)
-//   q6 = new planes of (LLL, LLR): xlo, xhi, ylo, yhi     q7 = ref LL, ref LR, ref LLL, ref LLR
+//   q3 = ref L, ref R, meta, 0          meta: bits 0-5 inherit mask of (LL, LR), bits 8-13 of (RL, RR),
+//                                             bit 16: (LL, LR) held, bit 17: (RL, RR) held
+//   q4 = new planes of (LL, LR): xlo, xhi, ylo, yhi       q5 = their zlo, zhi | zlo, zhi of (RL, RR)
+//   q6 = new planes of (RL, RR): xlo, xhi, ylo, yhi       q7 = ref LL, ref LR, ref RL, ref RR
 // Plane k of the left child of a pair is the parent's when bit k of the mask is set and the new plane otherwise;
 // the right child takes the other one.  A child reference is the record index of an interior node, or
 // kRefLeaf | slot in the primitive table (| kRefSphere for a sphere).
@@ -56,7 +56,7 @@ struct alignas(128) ChainNode {
     float n1xy[4];
     float n1z[2], n2z[2];
     float n2xy[4];
-    uint32_t ll, lr, lll, llr;
+    uint32_t ll, lr, rl, rr;
 };
 static_assert(sizeof(ChainNode) == 128, "ChainNode must be 128 bytes");
 constexpr uint32_t kRefLeaf = 0x80000000u;
