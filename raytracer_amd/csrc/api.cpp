@@ -577,15 +577,15 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     const rt::QueueView all{nullptr, nullptr, 0u, (uint32_t)n};
     const uint32_t grid = (uint32_t)std::min<uint64_t>(c->max_blocks, (n + 255) / 256);
     const uint32_t lds_bytes = trace_lds_bytes(c, s);
-    // Scenes beyond LDS size: one lane per ray (k_extend_lanes; teapot 5.4 vs 4.0 Grays/s of random rays, 1 M soup 0.51
-    // vs 0.30), over the chain records from 6 MB of tables on (queries are incoherent, so the records pay earlier than
-    // in a render: 60 k soup 1.23 vs 1.17 for the walk, 100 k 1.04 vs 0.78, 30 k 1.49 vs 1.67), else over the node table.
-    // RT_LANES_TRAVERSAL forces one of the two for any scene.  The instrumented kernel and the scan of the object list
-    // keep the lockstep kernel.
+    // Scenes beyond LDS size: one lane per ray (k_extend_lanes; teapot 5.4 vs 4.0 Grays/s of random rays, 1 M soup 0.58
+    // vs 0.30), over the chain records from 2 MB of tables on (queries are incoherent, so the records pay much earlier
+    // than in a render: 30 k soup, 3.4 MB, 1.88 vs 1.67 for the walk, 60 k 1.49 vs 1.17, 1 M 0.58 vs 0.30, 10 M 0.24 vs
+    // 0.12; the teapot, 1 MB: 3.9 vs 5.4), else over the node table.  RT_LANES_TRAVERSAL forces one of the two for any
+    // scene.  The instrumented kernel and the scan of the object list keep the lockstep kernel.
     const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
     const bool lanes = use_bvh && !count && (c->lanes_traversal != 0 || table_bytes > kTraceLanesBytes);
     if (lanes) {
-        const bool chain = s->dev.chain && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (6u << 20)));
+        const bool chain = s->dev.chain && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (2u << 20)));
         const uint32_t lanes_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cus * (chain ? 4u : 6u), (n + 255) / 256);
         rt::StackSpill spill{nullptr, lanes_grid * 256u};
         if (chain) {
