@@ -524,6 +524,35 @@ def test_random_scenes_differential(gpu_ctx, block):
         assert r.last_stats.rays_traced == cst.rays_traced
 
 
+@pytest.mark.parametrize("traversal", ["walk", "chain"])
+def test_random_scenes_with_the_lanes_traversals(monkeypatch, traversal):
+    """The random scenes again (shared edges, duplicated and degenerate triangles, coplanar axis-aligned meshes whose
+    boxes only differ by the 0.001 padding: exact ties, child boxes that do not share their parent's planes) through
+    the one-lane-per-ray closest-hit kernel and the one-lane-per-path render pipeline, with either traversal forced.
+    The chain records decide a node's grandchildren ahead of time and re-decide them from the stack; ties and
+    padded boxes are where that could go wrong.  Hits, sums and ray counts equal the oracle's bit for bit."""
+    from helpers import random_scene
+
+    monkeypatch.setenv("RT_LANES_TRAVERSAL", traversal)
+    ctx = Context(0)
+    ctx.set_pipeline(F.RT_PIPELINE_LANES)
+    for seed in range(24, 44):
+        desc, cs = random_scene(seed)
+        g, o = both(ctx, desc)
+        rays = random_rays(5000, (-2.5, -2.5, -2.5), (2.5, 2.5, 2.5), seed=seed, axis_aligned_fraction=0.3)
+        got, _ = g.trace_closest(rays, 1e-3, np.inf)
+        want, _ = o.trace_closest(rays, 1e-3, np.inf)
+        assert_hits_equal(got, want)
+        cam = camera_from_settings(cs, 64, 48)
+        rs = RenderSettings(64, 48, 0, 12, 4, mode=F.RT_MODE_LINEAR_MEAN, seed=200 + seed, background_color=(0.2, 0.3, 0.4))
+        r = Renderer(cam, g, rs)
+        gpu = r.render_sums()
+        cpu, cst = o.render(cam, rs, threads=16)
+        assert_images_equal(gpu, cpu)
+        assert r.last_stats.rays_traced == cst.rays_traced and r.last_stats.pipeline == F.RT_PIPELINE_LANES
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["cornell", "teapot", "spheres"])
 def test_converged_images_match_the_reference_rng(gpu_ctx, cornell, teapot, name):
     """Converged-image parity at equal spp (256 x 256, 256 spp, progressive mode): the GPU image (counter stream)
