@@ -98,6 +98,9 @@ struct rt_context {
     int lanes_traversal = 0; // +1 chain records, -1 stackless walk
     int lanes_first = 0;     // +1 bounce 0 by the per-bounce kernel in lockstep, -1 lanes from the camera ray on
     int lanes_waves = 0;     // waves per SIMD the kernel's registers are budgeted for
+    // launch shape of the lanes kernel over the walk table, 0 = default (RT_WALK_THREADS, RT_WALK_BLOCKS_PER_CU, RT_WALK_TOP_KB)
+    uint32_t walk_threads = 0, walk_blocks_per_cu = 0;
+    int64_t walk_top_bytes = -1;
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
     // wavefront workspace
@@ -128,8 +131,12 @@ struct rt_context {
 struct rt_scene {
     int device = 0;
     rt::SceneDev dev{};
-    void *blocks[10] = {};
+    void *blocks[12] = {};
     int n_blocks = 0;
+    // The chain records and the walk table are derived from the node table when a traversal first asks for them
+    // (ensure_chain / ensure_walk): dev.chain / dev.walk_nodes stay nullptr until then.
+    std::mutex derived_mutex;
+    uint32_t walk_region_bytes = 0; // bytes at the start of the walk table any prefix of which is a treetop
     std::vector<uint32_t> prim_of_slot;
     rt_scene_info info{};
     bool need_uv = false;
@@ -231,6 +238,70 @@ template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **ds
 
 } // namespace
 
+namespace {
+
+// LDS bytes every block of a launch stages the walk table's treetop in: blocks of `threads` threads, `blocks_per_cu` of
+// them resident on a CU with 160 KB of LDS (2 KB per block left for the kernels' own shared variables and the
+// allocation granularity).
+uint32_t top_bytes_for(const rt_scene *s, const rt_context *c, uint32_t blocks_per_cu) {
+    const uint32_t fit = ((160u * 1024u) / std::max(1u, blocks_per_cu) - 2048u) & ~31u;
+    uint32_t want = c->walk_top_bytes >= 0 ? (uint32_t)c->walk_top_bytes : fit;
+    want = std::min(want, fit) & ~31u;
+    return std::min(want, s->walk_region_bytes);
+}
+
+// The chain records (ChainNode) of a scene, built on the device from its node table the first time a traversal asks.
+int ensure_chain(rt_context *c, const rt_scene *cs) {
+    rt_scene *s = const_cast<rt_scene *>(cs);
+    std::lock_guard<std::mutex> lock(s->derived_mutex);
+    if (s->dev.chain) return RT_OK;
+    if (s->dev.n_prims > rt::kRefIndex) return set_error(RT_ERR_UNSUPPORTED, "the chain records hold 30-bit primitive slots");
+    void *p = nullptr;
+    const size_t bytes = (size_t)std::max<uint32_t>(1u, s->dev.n_prims - 1u) * sizeof(rt::ChainNode);
+    HIP_TRY(hipMalloc(&p, bytes));
+    rt::build_chain_nodes(c->stream, s->dev.nodes, s->dev.n_nodes, static_cast<rt::ChainNode *>(p));
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        (void)hipFree(p);
+        return set_error(RT_ERR_DEVICE, "building the BVH node records failed");
+    }
+    s->blocks[s->n_blocks++] = p;
+    s->dev.chain = static_cast<const rt::ChainNode *>(p);
+    s->info.device_bytes += bytes;
+    return RT_OK;
+}
+
+// The walk table (WalkNode) of a scene, built on the host from a copy of its node table the first time a traversal asks.
+int ensure_walk(rt_context *c, const rt_scene *cs) {
+    rt_scene *s = const_cast<rt_scene *>(cs);
+    std::lock_guard<std::mutex> lock(s->derived_mutex);
+    if (s->dev.walk_nodes) return RT_OK;
+    try {
+        std::vector<rt::Node> nodes(s->dev.n_nodes);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(nodes.data(), s->dev.nodes, nodes.size() * sizeof(rt::Node), hipMemcpyDeviceToHost));
+        std::vector<rt::WalkNode> table;
+        size_t region = 0;
+        std::string err;
+        if (!rt::build_walk_table(nodes.data(), nodes.size(), (158u * 1024u) / sizeof(rt::WalkNode), table, &region, err))
+            return set_error(RT_ERR_UNSUPPORTED, "%s", err.c_str());
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, table.size() * sizeof(rt::WalkNode)));
+        if (hipMemcpy(p, table.data(), table.size() * sizeof(rt::WalkNode), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(p);
+            return set_error(RT_ERR_DEVICE, "uploading the walk table failed");
+        }
+        s->blocks[s->n_blocks++] = p;
+        s->walk_region_bytes = (uint32_t)(region * sizeof(rt::WalkNode));
+        s->dev.walk_nodes = static_cast<const rt::WalkNode *>(p);
+        s->info.device_bytes += table.size() * sizeof(rt::WalkNode);
+    } catch (const std::bad_alloc &) {
+        return set_error(RT_ERR_OUT_OF_MEMORY, "out of host memory while building the walk table");
+    }
+    return RT_OK;
+}
+
+} // namespace
+
 // ------------------------------------------------------------------------------------------------------
 RT_API const char *rt_last_error(void) { return g_error.c_str(); }
 
@@ -266,6 +337,18 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
     if (const char *e = std::getenv("RT_LANES_WAVES")) {
         long v = std::strtol(e, nullptr, 10);
         if (v >= 4 && v <= 8 && v != 7) c->lanes_waves = (int)v;
+    }
+    if (const char *e = std::getenv("RT_WALK_THREADS")) {
+        long v = std::strtol(e, nullptr, 10);
+        if (v == 256 || v == 512 || v == 768 || v == 1024) c->walk_threads = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("RT_WALK_BLOCKS_PER_CU")) {
+        long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 8) c->walk_blocks_per_cu = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("RT_WALK_TOP_KB")) {
+        long v = std::strtol(e, nullptr, 10);
+        if (v >= 0 && v <= 150) c->walk_top_bytes = v * 1024;
     }
     c->cus = (uint32_t)std::max(1, prop.multiProcessorCount);
     c->max_blocks = c->cus * 8u;
@@ -415,26 +498,9 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
     }
     s->dev.n_nodes = d_nodes ? (uint32_t)n_nodes_device : (uint32_t)hs.nodes.size();
     s->dev.n_prims = (uint32_t)hs.prims.size();
-    // The 128-byte records of the stack traversal, derived on the device from the node table just uploaded.
     s->dev.depth = hs.depth;
     s->dev.root_ref = root.leaf == rt::kInterior ? 0u
                                                  : (rt::kRefLeaf | ((root.leaf & rt::kSphereBit) ? rt::kRefSphere : 0u) | (root.leaf & ~rt::kSphereBit));
-    if (s->dev.n_prims <= rt::kRefIndex) {
-        void *p = nullptr;
-        const size_t wide_bytes = (size_t)std::max<uint32_t>(1u, s->dev.n_prims - 1u) * sizeof(rt::ChainNode);
-        if (hipMalloc(&p, wide_bytes) != hipSuccess) {
-            rt_scene_destroy(s);
-            return set_error(RT_ERR_OUT_OF_MEMORY, "out of device memory for the BVH node records");
-        }
-        s->blocks[s->n_blocks++] = p;
-        s->dev.chain = static_cast<const rt::ChainNode *>(p);
-        rt::build_chain_nodes(c->stream, s->dev.nodes, s->dev.n_nodes, static_cast<rt::ChainNode *>(p));
-        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
-            rt_scene_destroy(s);
-            return set_error(RT_ERR_DEVICE, "building the BVH node records failed");
-        }
-        bytes += wide_bytes;
-    }
     s->dev.n_materials = (uint32_t)hs.materials.size();
     s->dev.n_textures = (uint32_t)hs.textures.size();
     s->need_uv = hs.need_uv;
@@ -585,14 +651,19 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
     const bool lanes = use_bvh && !count && (c->lanes_traversal != 0 || table_bytes > kTraceLanesBytes);
     if (lanes) {
-        const bool chain = s->dev.chain && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (2u << 20)));
+        const bool chain = s->dev.n_prims <= rt::kRefIndex && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (2u << 20)));
+        if (int rc = chain ? ensure_chain(c, s) : ensure_walk(c, s)) return rc;
         const uint32_t lanes_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cus * (chain ? 4u : 6u), (n + 255) / 256);
         rt::StackSpill spill{nullptr, lanes_grid * 256u};
+        rt::SceneDev dev = s->dev;
         if (chain) {
+            // at most two pending entries per interior level (see StackWalk)
             if (int rc = c->stack_spill.ensure((size_t)(2u * s->dev.depth + 2u) * spill.stride)) return rc;
             spill.spill = c->stack_spill.ptr;
+        } else {
+            dev.top_bytes = top_bytes_for(s, c, 6u);
         }
-        rt::launch_extend_lanes(c->stream, lanes_grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, t_min, t_max,
+        rt::launch_extend_lanes(c->stream, lanes_grid, dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, t_min, t_max,
                                 spill, chain);
     } else {
         rt::launch_extend(c->stream, grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, all, t_min, t_max, use_bvh != 0,
@@ -711,7 +782,10 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
     }
     const bool lanes = pipeline == RT_PIPELINE_LANES;
-    const bool lanes_chain = lanes && s->dev.chain && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (48u << 20)));
+    const bool lanes_chain = lanes && s->dev.n_prims <= rt::kRefIndex &&
+                             (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (48u << 20)));
+    if (lanes)
+        if (int rc = lanes_chain ? ensure_chain(c, s) : ensure_walk(c, s)) return rc;
     const bool lanes_lockstep_first = c->lanes_first ? c->lanes_first > 0 : !lanes_chain;
     const int lanes_waves = s->has_mix ? 4 : c->lanes_waves ? c->lanes_waves : (lanes_chain ? 4 : 6);
     if (s->has_mix && pipeline != RT_PIPELINE_PATHS && pipeline != RT_PIPELINE_PATHS_LDS && !lanes)
@@ -741,7 +815,25 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
                                    : big_blocks    ? 1u
                                    : eight_waves   ? 8u
                                                    : (table_bytes <= 256u * 1024u ? 24u : 6u);
-    const uint32_t grid = std::min(c->cus * blocks_per_cu, chunks);
+    uint32_t grid = std::min(c->cus * blocks_per_cu, chunks);
+    // The lanes kernel over the walk table stages the table's treetop in LDS once per block, so it runs in blocks of
+    // `walk_threads` threads, `walk_blocks_per_cu` to a CU, each taking the survivors of grid / walk_grid blocks of the
+    // bounce-0 launch (which keeps 256-thread blocks).
+    const bool lanes_walk = lanes && !lanes_chain;
+    // Measured on the teapot (1 MB of tables; default camera / lit, Grays/s), threads x blocks per CU, treetop bytes:
+    // no treetop 3.74 / 6.62; 256 x 6, 24 KB 4.40 / 7.10; 512 x 3, 51 KB 4.63 / 7.37; 768 x 2, 78 KB 4.81 / 7.57; 1024 x 1,
+    // 158 KB 4.36 / 7.06 and 512 x 2, 78 KB 4.08 / 6.67 (four waves per SIMD instead of six hide too little latency);
+    // eight waves per SIMD (64 registers, spills) 1024 x 2 4.50 / 7.05.
+    const uint32_t walk_threads = c->walk_threads ? c->walk_threads : 768u;
+    const uint32_t walk_blocks_per_cu = c->walk_blocks_per_cu ? c->walk_blocks_per_cu : std::max(1u, blocks_per_cu * 256u / walk_threads);
+    uint32_t walk_grid = grid;
+    rt::SceneDev dev = s->dev;
+    if (lanes_walk) {
+        walk_grid = std::min(c->cus * walk_blocks_per_cu, chunks);
+        const uint32_t segs = std::min(32u, std::max(1u, (grid + walk_grid - 1) / walk_grid));
+        grid = walk_grid * segs;
+        dev.top_bytes = top_bytes_for(s, c, walk_blocks_per_cu);
+    }
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
     if (int rc = ensure_render(c, lanes ? 0 : slots, lanes ? 0 : (size_t)grid * cap, st->max_depth, grid)) return rc;
     if (int rc = c->radiance.ensure(slots)) return rc;
@@ -753,7 +845,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     }
     const uint32_t block_threads = big_blocks ? 1024u : 256u;
     rt::StackSpill spill{nullptr, grid * block_threads};
-    if (stack) {
+    if (stack) { // at most two pending entries per interior level (see StackWalk)
         if (int rc = c->stack_spill.ensure((size_t)(2u * s->dev.depth + 2u) * spill.stride)) return rc;
         spill.spill = c->stack_spill.ptr;
     }
@@ -804,8 +896,8 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             HIP_TRY(hipMemsetAsync(c->early.ptr + grid, 0, rows, c->stream));
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             if (lanes)
-                rt::launch_paths_lanes(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->counts.ptr, c->early.ptr, s->need_uv,
-                                       s->has_mix, lanes_waves, spill, lanes_lockstep_first, lanes_chain);
+                rt::launch_paths_lanes(c->stream, grid, dev, P, ps, n, cap, c->queue[0].ptr, c->counts.ptr, c->early.ptr, s->need_uv,
+                                       s->has_mix, lanes_waves, spill, lanes_lockstep_first, lanes_chain, walk_threads, walk_grid);
             else
                 rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr,
                                  c->early.ptr, s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves);

@@ -57,9 +57,12 @@ constexpr int kStackEntriesInLds = RT_STACK_K;
 // arrays are not touched.  `counts` / `early` are the [max_depth + 1][grid] tables, rows 1.. zeroed by the caller.
 void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
                         uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *counts, uint32_t *early, bool need_uv, bool has_mix,
-                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep, bool chain);
-// `chain`: traverse the chain records with the per-lane stack; otherwise the stackless walk over the node table
-// (always from the camera ray on).
+                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep, bool chain, uint32_t walk_threads,
+                        uint32_t walk_grid);
+// `chain`: traverse the chain records with the per-lane stack (needs sc.chain); otherwise the stackless walk over the
+// walk table (needs sc.walk_nodes), whose treetop (sc.top_bytes) every block stages in LDS: then the lanes kernel runs
+// `walk_grid` blocks of `walk_threads` threads (256, 512 or 1024), `walk_grid` dividing `grid` with a quotient of at
+// most 32, while bounce 0 (when in lockstep) and the tables keep `grid` blocks of 256.
 void launch_sum_counts(hipStream_t s, const uint32_t *counts, const uint32_t *early, uint32_t n_blocks, uint32_t n_rows,
                        unsigned long long *totals);
 

@@ -28,6 +28,23 @@ constexpr int kBlock = 256;
 constexpr uint32_t kDrawBits = 28u;
 constexpr uint32_t kDrawMask = (1u << kDrawBits) - 1u;
 
+// The wave's mask of lanes where `pred` holds, straight from the compare (HIP's __ballot takes an int, which makes
+// the compiler materialise the predicate in a register and compare it again).
+__device__ __forceinline__ unsigned long long ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
+// A pointer every lane holds the same value of, as a value the compiler knows to be uniform (so that it lives in
+// scalar registers, which the scalar-base form of a global load needs).
+template <class T> __device__ __forceinline__ T *uniform_pointer(T *p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<T *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
+
+// The LDS address (byte offset within the workgroup's LDS) of an object in shared memory.
+__device__ __forceinline__ uint32_t lds_address(const void *shared) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)shared;
+}
+
 __device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
 __device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
 __device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -315,8 +332,9 @@ struct StackWalk {
         }
         cur = next;
     }
-    __device__ __forceinline__ bool at_leaf() const { return cur != kRefNone && (cur & kRefLeaf) != 0u; }
-    __device__ __forceinline__ bool at_node() const { return (cur & kRefLeaf) == 0u; } // kRefNone has the leaf bit set
+    // kRefLeaf is the sign bit and kRefNone is -1: a leaf reference is < -1, a node reference >= 0
+    __device__ __forceinline__ bool at_leaf() const { return (int32_t)cur < -1; }
+    __device__ __forceinline__ bool at_node() const { return (int32_t)cur >= 0; }
 
     // cur names a primitive: the 48 bytes of its record (read no further: a primitive record read as 64 bytes would
     // reach into the next cache line more often).  Measured and rejected: primitive records at a 64-byte stride,
@@ -397,13 +415,15 @@ struct StackWalk {
 };
 
 // The stackless pre-order walk (traverse() above) in the same begin / step form, for one lane per path over tables
-// that sit in the caches: cur is the index of the node to test next, or kRefLeaf | slot when the node just tested
-// was a leaf whose box is hit and its primitive test is still due (then `resume` is the node to go on with).
-struct PreorderWalk {
+// that sit in the caches, on the walk table (WalkNode, rt_device.h): cur is the byte offset of the node to test next,
+// or kRefLeaf | slot when the node just tested was a leaf whose box is hit and its primitive test is still due (then
+// `resume` is where to go on), or kRefNone when the walk is over.  Nodes below `top_bytes` are read from the block's
+// LDS copy of the treetop, the others through the caches.
+struct TopWalk {
     V3 o, d, inv;
     float tmin;
     Closest best;
-    uint32_t cur, resume, end;
+    uint32_t cur, resume;
 
     __device__ __forceinline__ void init(uint2 *, const StackSpill &) { cur = kRefNone; }
     __device__ __forceinline__ void begin(float4, float4, uint32_t, V3 origin, V3 dir, float t_min, float t_max) {
@@ -412,29 +432,45 @@ struct PreorderWalk {
         inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
         best = Closest{t_max, kMissSlot, 0.0f, 0.0f};
         tmin = in_vgpr(t_min);
-        cur = 0u; // the root's own box is node 0's
+        cur = 0u; // the root's own box is the first record's
     }
-    __device__ __forceinline__ bool at_leaf() const { return cur != kRefNone && (cur & kRefLeaf) != 0u; }
-    __device__ __forceinline__ bool at_node() const { return (cur & kRefLeaf) == 0u; }
+    __device__ __forceinline__ bool at_leaf() const { return (int32_t)cur < -1; } // kRefLeaf is the sign bit, kRefNone is -1
+    __device__ __forceinline__ bool at_node() const { return (int32_t)cur >= 0; }
     __device__ __forceinline__ void step_leaf(const float4 *__restrict__ prims) {
         const uint32_t slot = cur & kRefIndex;
         if (cur & kRefSphere)
             sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
         else
             tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
-        cur = resume < end ? resume : kRefNone;
+        cur = resume;
     }
-    __device__ __forceinline__ void step_node(const float4 *__restrict__ nodes) {
-        const float4 nlo = nodes[2 * (size_t)cur], nhi = nodes[2 * (size_t)cur + 1];
+    // `lds_top`: LDS address (byte offset within the block's LDS) of the staged treetop.  Lanes below the treetop read
+    // their record through the caches (scalar base + 32-bit offset), the others from LDS, in ONE round: both kinds of
+    // loads are issued under their own execution mask and awaited together, so a round costs the longer of the two
+    // latencies once, and the four 16-byte halves land in the same two register quads (each lane is written by the
+    // one load that was issued for it).  Written in assembly because the compiler turns a two-sided load into generic
+    // (flat) loads and splits them.
+    __device__ __forceinline__ void step_node(const float4 *__restrict__ nodes, uint32_t lds_top, uint32_t top_bytes) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f lo4, hi4;
+        unsigned long long saved;
+        const unsigned long long in_top = ballot(cur < top_bytes);
+        asm volatile("s_and_saveexec_b64 %[saved], %[top]\n\t"
+                     "ds_read_b128 %[lo], %[la]\n\t"
+                     "ds_read_b128 %[hi], %[la] offset:16\n\t"
+                     "s_andn2_b64 exec, %[saved], %[top]\n\t"
+                     "global_load_dwordx4 %[lo], %[off], %[base]\n\t"
+                     "global_load_dwordx4 %[hi], %[off], %[base] offset:16\n\t"
+                     "s_mov_b64 exec, %[saved]\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : [lo] "=&v"(lo4), [hi] "=&v"(hi4), [saved] "=&s"(saved)
+                     : [top] "s"(in_top), [la] "v"(cur + lds_top), [off] "v"(cur), [base] "s"(nodes)
+                     : "memory");
+        const float4 nlo = make_float4(lo4.x, lo4.y, lo4.z, lo4.w), nhi = make_float4(hi4.x, hi4.y, hi4.z, hi4.w);
         const bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
-        const uint32_t leaf = f2u(nhi.w);
-        const uint32_t next = hit ? cur + 1u : f2u(nhi.z);
-        if (hit && leaf != kInterior) {
-            resume = next;
-            cur = kRefLeaf | ((leaf & kSphereBit) ? kRefSphere : 0u) | (leaf & ~kSphereBit);
-        } else {
-            cur = next < end ? next : kRefNone;
-        }
+        const uint32_t on_hit = f2u(nhi.w), on_miss = f2u(nhi.z);
+        if (hit && (on_hit & kRefLeaf)) resume = on_miss;
+        cur = hit ? on_hit : on_miss;
     }
 };
 
@@ -842,7 +878,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
     V3 o{}, d{}, inv{};
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
     for (;;) {
-        const unsigned long long idle_mask = __ballot(!have);
+        const unsigned long long idle_mask = ballot(!have);
         const uint32_t n_idle = __popcll(idle_mask);
         if (!exhausted && (n_idle >= RT_REFILL_LANES)) {
             uint32_t base = 0;
@@ -870,7 +906,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
                 }
             }
         }
-        if (__ballot(have) == 0ull) {
+        if (ballot(have) == 0ull) {
             if (exhausted) break;
             continue;
         }
@@ -1028,9 +1064,9 @@ __device__ __forceinline__ int shade_path(const SceneDev &sc, float4 root_lo, fl
 __device__ __forceinline__ void compact_survivors(int outcome, uint32_t slot, uint32_t lane, uint32_t *s_out,
                                                   uint32_t *s_early, uint32_t *__restrict__ queue_out, uint32_t seg) {
     const bool alive = outcome == kPathAlive;
-    unsigned long long early = __ballot(outcome == kPathEndedByEarlyMiss);
+    unsigned long long early = ballot(outcome == kPathEndedByEarlyMiss);
     if (early && lane == 0) atomicAdd(s_early, (uint32_t)__popcll(early));
-    unsigned long long mask = __ballot(alive);
+    unsigned long long mask = ballot(alive);
     if (mask) {
         uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
         uint32_t total = __popcll(mask);
@@ -1265,33 +1301,50 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
 // segment of `queue` (`pool[b]` entries), whose first rays the caller has counted already.
 // CHAIN: the stack traversal over the 128-byte chain records (scenes read from HBM); otherwise the stackless walk
 // over the 32-byte node table (scenes that sit in the L2s).
-template <bool NEED_UV, bool HAS_MIX, int WAVES, int K, bool FROM_CAMERA, bool CHAIN = true>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : WAVES))) void k_paths_lanes(
+// THREADS: threads per block.  The walk table's treetop is staged once per block, so larger blocks share a larger
+// treetop; work is claimed per wave, nothing else depends on the block size.
+// `segs` (!FROM_CAMERA): the block takes the survivors of `segs` consecutive blocks of the bounce-0 launch, i.e. the
+// queue segments [blockIdx.x * segs, (blockIdx.x + 1) * segs) (at most kMaxSegs).
+constexpr uint32_t kMaxSegs = 32;
+template <bool NEED_UV, bool HAS_MIX, int WAVES, int K, bool FROM_CAMERA, bool CHAIN = true, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : WAVES))) void k_paths_lanes(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, const uint32_t *__restrict__ queue,
-    const uint32_t *__restrict__ pool, uint32_t *__restrict__ ray_counts, StackSpill spill) {
+    const uint32_t *__restrict__ pool, uint32_t *__restrict__ ray_counts, StackSpill spill, uint32_t segs) {
+    static_assert(!CHAIN || THREADS == kBlock, "the stack area of the chain walk is laid out for 256-thread blocks");
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_next, s_rays;
-    const float4 *__restrict__ chain = reinterpret_cast<const float4 *>(CHAIN ? static_cast<const void *>(sc.chain) : static_cast<const void *>(sc.nodes));
+    __shared__ uint32_t s_first[kMaxSegs + 1]; // !FROM_CAMERA: item index of the first entry of each of the block's segments
+    const float4 *__restrict__ chain = uniform_pointer(reinterpret_cast<const float4 *>(CHAIN ? static_cast<const void *>(sc.chain) : static_cast<const void *>(sc.walk_nodes)));
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
     if (threadIdx.x == 0) {
         s_next = 0u;
         s_rays = 0u;
+        if (!FROM_CAMERA) {
+            uint32_t acc = 0;
+            for (uint32_t i = 0; i < segs; ++i) {
+                s_first[i] = acc;
+                acc += pool[blockIdx.x * segs + i];
+            }
+            s_first[segs] = acc;
+        }
+    }
+    if constexpr (!CHAIN) { // the treetop of the walk table
+        const uint32_t n4 = sc.top_bytes / 16u;
+        for (uint32_t i = threadIdx.x; i < n4; i += THREADS) s_scene[i] = chain[i];
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t seg = blockIdx.x * cap;
     uint32_t my_items;
     if (FROM_CAMERA) {
         const uint32_t chunks = (n_slots + kBlock - 1) / kBlock;
         my_items = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
     } else {
-        my_items = pool[blockIdx.x];
+        my_items = s_first[segs];
     }
 
-    typename std::conditional<CHAIN, StackWalk<K, kBlock>, PreorderWalk>::type walk;
+    typename std::conditional<CHAIN, StackWalk<K, kBlock>, TopWalk>::type walk;
     walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
-    if constexpr (!CHAIN) walk.end = sc.n_nodes;
     Segment g{};
     uint32_t slot = 0, s_local = 0, pixel = 0, n_rays = 0;
 
@@ -1299,8 +1352,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
     walk.cur = kRefNone;
     for (;;) {
         const bool finished = have && walk.cur == kRefNone;
-        const uint32_t n_fin = __popcll(__ballot(finished));
-        const uint32_t n_empty = __popcll(__ballot(!have));
+        const uint32_t n_fin = __popcll(ballot(finished));
+        const uint32_t n_empty = __popcll(ballot(!have));
         const uint32_t n_busy = 64u - n_fin - n_empty;
         // Lanes that could be put to work now, against the lanes this wave can still use: serve them once they are
         // a quarter of the wave, or when nothing else is left to do.
@@ -1321,7 +1374,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                     if (outcome == kPathEndedByEarlyMiss) ++n_rays;
                 }
             }
-            const unsigned long long empty_mask = __ballot(!have);
+            const unsigned long long empty_mask = ballot(!have);
             if (!exhausted && empty_mask) {
                 const uint32_t want = __popcll(empty_mask);
                 uint32_t base = 0;
@@ -1332,7 +1385,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                     const uint32_t item = base + __popcll(empty_mask & ((1ull << lane) - 1ull));
                     if (!FROM_CAMERA) {
                         if (item < my_items) {
-                            slot = queue[seg + item];
+                            uint32_t sg = 0;
+                            while (item >= s_first[sg + 1]) ++sg;
+                            slot = queue[(size_t)(blockIdx.x * segs + sg) * cap + (item - s_first[sg])];
                             const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
                             g.o = xyz(o4);
                             g.d = xyz(d4);
@@ -1358,7 +1413,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                     }
                 }
             }
-            if (__ballot(have) == 0ull) {
+            if (ballot(have) == 0ull) {
                 if (exhausted) break;
                 continue;
             }
@@ -1371,12 +1426,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
         // nothing else is left): a wave then runs the node code or the triangle code in a round, not both.
 #pragma nounroll
         for (int r = 0; r < (CHAIN ? RT_ROUNDS_CHAIN : RT_ROUNDS_WALK); ++r) {
-            const bool leaf_lane = have && walk.at_leaf(), node_lane = have && walk.at_node();
-            const uint32_t n_leaf = __popcll(__ballot(leaf_lane)), n_node = __popcll(__ballot(node_lane));
+            // a lane without a path has cur == kRefNone, which is neither: `have` needs no look here
+            const bool leaf_lane = walk.at_leaf(), node_lane = walk.at_node();
+            const uint32_t n_leaf = __popcll(ballot(leaf_lane)), n_node = __popcll(ballot(node_lane));
             if (n_node == 0u || n_leaf * RT_LEAF_DIV >= n_node + n_leaf) {
                 if (leaf_lane) walk.step_leaf(prims);
             } else {
-                if (node_lane) walk.step_node(chain);
+                if constexpr (CHAIN) {
+                    if (node_lane) walk.step_node(chain);
+                } else {
+                    if (node_lane) walk.step_node(chain, lds_address(s_scene), sc.top_bytes);
+                }
             }
         }
     }
@@ -1395,25 +1455,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 
     float tmin, float tmax, StackSpill spill) {
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_next;
-    const float4 *__restrict__ chain = reinterpret_cast<const float4 *>(CHAIN ? static_cast<const void *>(sc.chain) : static_cast<const void *>(sc.nodes));
+    const float4 *__restrict__ chain = uniform_pointer(reinterpret_cast<const float4 *>(CHAIN ? static_cast<const void *>(sc.chain) : static_cast<const void *>(sc.walk_nodes)));
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
     if (threadIdx.x == 0) s_next = 0u;
+    if constexpr (!CHAIN) { // the treetop of the walk table
+        const uint32_t n4 = sc.top_bytes / 16u;
+        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) s_scene[i] = chain[i];
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t chunks = (n + kBlock - 1) / kBlock;
     const uint32_t pool = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
 
-    typename std::conditional<CHAIN, StackWalk<K, kBlock>, PreorderWalk>::type walk;
+    typename std::conditional<CHAIN, StackWalk<K, kBlock>, TopWalk>::type walk;
     walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
-    if constexpr (!CHAIN) walk.end = sc.n_nodes;
     uint32_t slot = 0;
     bool have = false, exhausted = false;
     walk.cur = kRefNone;
     for (;;) {
         const bool finished = have && walk.cur == kRefNone;
-        const uint32_t n_fin = __popcll(__ballot(finished));
-        const uint32_t n_empty = __popcll(__ballot(!have));
+        const uint32_t n_fin = __popcll(ballot(finished));
+        const uint32_t n_empty = __popcll(ballot(!have));
         const uint32_t n_busy = 64u - n_fin - n_empty;
         const uint32_t idle = n_fin + (exhausted ? 0u : n_empty);
         const uint32_t usable = 64u - (exhausted ? n_empty : 0u);
@@ -1422,7 +1485,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 
                 hits[slot] = make_float4(walk.best.t, u2f(walk.best.slot), walk.best.u, walk.best.v);
                 have = false;
             }
-            const unsigned long long empty_mask = __ballot(!have);
+            const unsigned long long empty_mask = ballot(!have);
             if (!exhausted && empty_mask) {
                 const uint32_t want = __popcll(empty_mask);
                 uint32_t base = 0;
@@ -1438,19 +1501,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 
                     }
                 }
             }
-            if (__ballot(have) == 0ull) {
+            if (ballot(have) == 0ull) {
                 if (exhausted) break;
                 continue;
             }
         }
 #pragma nounroll
         for (int r = 0; r < (CHAIN ? RT_ROUNDS_CHAIN : RT_ROUNDS_WALK); ++r) {
-            const bool leaf_lane = have && walk.at_leaf(), node_lane = have && walk.at_node();
-            const uint32_t n_leaf = __popcll(__ballot(leaf_lane)), n_node = __popcll(__ballot(node_lane));
+            // a lane without a path has cur == kRefNone, which is neither: `have` needs no look here
+            const bool leaf_lane = walk.at_leaf(), node_lane = walk.at_node();
+            const uint32_t n_leaf = __popcll(ballot(leaf_lane)), n_node = __popcll(ballot(node_lane));
             if (n_node == 0u || n_leaf * RT_LEAF_DIV >= n_node + n_leaf) {
                 if (leaf_lane) walk.step_leaf(prims);
             } else {
-                if (node_lane) walk.step_node(chain);
+                if constexpr (CHAIN) {
+                    if (node_lane) walk.step_node(chain);
+                } else {
+                    if (node_lane) walk.step_node(chain, lds_address(s_scene), sc.top_bytes);
+                }
             }
         }
     }
@@ -1554,7 +1622,7 @@ void launch_extend_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const
         hipLaunchKernelGGL((k_extend_lanes<K, true>), dim3(grid), dim3(kBlock), (uint32_t)(K * kBlock * sizeof(uint2)), s, sc, ray_o,
                            ray_d, hits, n, tmin, tmax, spill);
     else
-        hipLaunchKernelGGL((k_extend_lanes<K, false>), dim3(grid), dim3(kBlock), 0, s, sc, ray_o, ray_d, hits, n, tmin, tmax, spill);
+        hipLaunchKernelGGL((k_extend_lanes<K, false>), dim3(grid), dim3(kBlock), sc.top_bytes, s, sc, ray_o, ray_d, hits, n, tmin, tmax, spill);
 }
 
 void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
@@ -1634,28 +1702,49 @@ void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue0, queue1, counts, early);
 }
 
+namespace {
+using LanesKernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, StackSpill,
+                             uint32_t);
+
+// The instance of k_paths_lanes over the walk table for a block size and a register budget.
+template <bool FROM_CAMERA, int THREADS, int WAVES>
+LanesKernel walk_kernel(bool need_uv, bool has_mix) {
+    constexpr int K = kStackEntriesInLds;
+    return has_mix   ? k_paths_lanes<true, true, 4, K, FROM_CAMERA, false, THREADS>
+           : need_uv ? k_paths_lanes<true, false, WAVES, K, FROM_CAMERA, false, THREADS>
+                     : k_paths_lanes<false, false, WAVES, K, FROM_CAMERA, false, THREADS>;
+}
+template <bool FROM_CAMERA>
+LanesKernel walk_kernel(uint32_t threads, int waves, bool need_uv, bool has_mix) {
+    if (threads == 1024u) return waves >= 8 ? walk_kernel<FROM_CAMERA, 1024, 8>(need_uv, has_mix) : walk_kernel<FROM_CAMERA, 1024, 4>(need_uv, has_mix);
+    if (threads == 768u) return walk_kernel<FROM_CAMERA, 768, 6>(need_uv, has_mix);
+    if (threads == 512u)
+        return waves >= 8   ? walk_kernel<FROM_CAMERA, 512, 8>(need_uv, has_mix)
+               : waves >= 6 ? walk_kernel<FROM_CAMERA, 512, 6>(need_uv, has_mix)
+                            : walk_kernel<FROM_CAMERA, 512, 4>(need_uv, has_mix);
+    return waves >= 6 ? walk_kernel<FROM_CAMERA, kBlock, 6>(need_uv, has_mix) : walk_kernel<FROM_CAMERA, kBlock, 4>(need_uv, has_mix);
+}
+} // namespace
+
 void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const RenderParams &P, const PathState &st,
                         uint32_t n_slots, uint32_t cap, uint32_t *queue, uint32_t *counts, uint32_t *early, bool need_uv, bool has_mix,
-                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep, bool chain) {
+                        int waves, const StackSpill &spill, bool camera_rays_in_lockstep, bool chain, uint32_t walk_threads,
+                        uint32_t walk_grid) {
     constexpr int K = kStackEntriesInLds;
-    if (!chain) { // the stackless walk: no stack memory
-        using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, StackSpill);
-        Kernel kernel;
+    if (!chain) { // the stackless walk: no stack memory; LDS holds the treetop of the walk table
         if (camera_rays_in_lockstep) {
             const QueueView all{nullptr, nullptr, cap, n_slots};
             auto first = has_mix ? k_bounce<true, false, true, true, 0> : need_uv ? k_bounce<true, false, true, false, 0> : k_bounce<true, false, false, false, 0>;
             hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), 0, s, sc, P, st, all, queue, counts + grid, early + grid, spill);
             if (P.max_depth < 2u) return;
-            kernel = has_mix      ? k_paths_lanes<true, true, 4, K, false, false>
-                     : waves >= 6 ? (need_uv ? k_paths_lanes<true, false, 6, K, false, false> : k_paths_lanes<false, false, 6, K, false, false>)
-                                  : (need_uv ? k_paths_lanes<true, false, 4, K, false, false> : k_paths_lanes<false, false, 4, K, false, false>);
-        } else {
-            kernel = has_mix      ? k_paths_lanes<true, true, 4, K, true, false>
-                     : waves >= 6 ? (need_uv ? k_paths_lanes<true, false, 6, K, true, false> : k_paths_lanes<false, false, 6, K, true, false>)
-                                  : (need_uv ? k_paths_lanes<true, false, 4, K, true, false> : k_paths_lanes<false, false, 4, K, true, false>);
         }
+        LanesKernel kernel = camera_rays_in_lockstep ? walk_kernel<false>(walk_threads, waves, need_uv, has_mix)
+                                                     : walk_kernel<true>(walk_threads, waves, need_uv, has_mix);
+        if (sc.top_bytes > 48u * 1024u)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc.top_bytes);
         uint32_t *ray_counts = counts + (size_t)(camera_rays_in_lockstep ? 2u : 1u) * grid;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, s, sc, P, st, n_slots, cap, queue, counts + grid, ray_counts, spill);
+        hipLaunchKernelGGL(kernel, dim3(walk_grid), dim3(walk_threads), sc.top_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid,
+                           ray_counts, spill, grid / walk_grid);
         return;
     }
     const uint32_t stack_bytes = (uint32_t)(K * kBlock * sizeof(uint2));
@@ -1665,8 +1754,7 @@ void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const 
         hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), stack_bytes, s, sc, P, st, all, queue, counts + grid, early + grid, spill);
         if (P.max_depth < 2u) return;
     }
-    using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, StackSpill);
-    Kernel kernel;
+    LanesKernel kernel;
 #define RT_LANES_KERNEL(FROM_CAMERA)                                                                                             \
     (has_mix      ? k_paths_lanes<true, true, 4, K, FROM_CAMERA>                                                                   \
      : waves >= 8 ? (need_uv ? k_paths_lanes<true, false, 8, K, FROM_CAMERA> : k_paths_lanes<false, false, 8, K, FROM_CAMERA>)     \
@@ -1680,7 +1768,7 @@ void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const 
 #undef RT_LANES_KERNEL
     // rays beyond those the tables already hold: bounce 0's survivors are row 1, so the lanes' own count is row 2
     uint32_t *ray_counts = counts + (size_t)(camera_rays_in_lockstep ? 2u : 1u) * grid;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), stack_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid, ray_counts, spill);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), stack_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid, ray_counts, spill, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------------

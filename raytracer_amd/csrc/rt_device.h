@@ -64,6 +64,19 @@ constexpr uint32_t kRefSphere = 0x40000000u;
 constexpr uint32_t kRefIndex = 0x3FFFFFFFu;
 constexpr uint32_t kRefNone = 0xFFFFFFFFu;
 
+// The same tree a third time, for the one-lane-per-path walk over scenes that sit in the L2s: the 32-byte nodes of the
+// pre-order table with BOTH successors explicit, as byte offsets into this table (what an LDS read and a
+// base-plus-offset global read want as their address):
+//   skip = where BvhNode::hit goes on after this node's box is missed, or after a leaf (the pre-order table's skip)
+//   leaf = interior node: where it goes on after the box is hit (the left child);
+//          leaf: kRefLeaf | kRefSphere (for a sphere) | slot in the primitive table
+// kRefNone as a successor ends the walk.  With explicit successors the order of the records is free: the table starts
+// with the "treetop", the nodes nearest the root taken level by level (so a node's parent is in it whenever the node
+// is), as many as the LDS budget allows, in pre-order among themselves; the other nodes follow in pre-order.  Every
+// block stages the treetop in LDS and a lane reads node `cur` from LDS when cur < top_bytes, else through the caches.
+// Visiting order, box tests and primitive tests are the pre-order walk's, hence the reference's.
+typedef Node WalkNode;
+
 // An object's own bounding box (`Hittable::bounding_box`), already padded; input of the tree builders.
 struct BuildBox {
     float lo[3];
@@ -134,8 +147,10 @@ struct SceneDev {
     const uint8_t *texels;
     const uint32_t *slot_of_prim; // primitive ID -> slot in `prims` (object-list order for World::hit)
     const ChainNode *chain;       // n_prims - 1 records; nullptr when the table was not built
+    const WalkNode *walk_nodes;   // n_nodes records, treetop first; nullptr when the table was not built
+    uint32_t top_bytes;           // bytes of walk_nodes that form the treetop (a multiple of 32)
     uint32_t root_ref;            // child reference of the root (a leaf reference for a one-primitive scene)
-    uint32_t depth;               // levels of the tree: the traversal stack never holds more than depth - 1 entries
+    uint32_t depth;               // levels of the tree; the chain walk's stack holds at most 2 entries per interior level
     uint32_t n_nodes;
     uint32_t n_prims;
     uint32_t n_materials;

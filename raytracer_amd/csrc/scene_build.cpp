@@ -413,4 +413,71 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err, c
     return RT_OK;
 }
 
+bool build_walk_table(const Node *nodes, size_t n, size_t max_region_nodes, std::vector<WalkNode> &out, size_t *region_nodes,
+                      std::string &err) {
+    if (n == 0 || n > (1ull << 26)) {
+        err = "the walk table addresses its nodes by 31-bit byte offsets: at most 2^26 nodes";
+        return false;
+    }
+    // levels: in pre-order a node's children are i + 1 and the node after the left child's subtree
+    std::vector<uint32_t> level(n, 0u);
+    uint32_t deepest = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (nodes[i].leaf != kInterior) continue;
+        const size_t left = i + 1, right = left < n ? nodes[left].skip : n;
+        if (right >= n) {
+            err = "malformed node table";
+            return false;
+        }
+        level[left] = level[right] = level[i] + 1u;
+        deepest = std::max(deepest, level[i] + 1u);
+    }
+    // the region: whole levels while they fit, then the leftmost nodes of the next one
+    std::vector<size_t> per_level(deepest + 1u, 0);
+    for (size_t i = 0; i < n; ++i) ++per_level[level[i]];
+    const size_t budget = std::min(n, max_region_nodes);
+    std::vector<size_t> first_of_level(deepest + 2u, 0); // region position of a level's first node
+    uint32_t partial = 0;                                // the level that is taken in part (or deepest + 1)
+    size_t partial_count = 0, taken = 0;
+    for (partial = 0; partial <= deepest; ++partial) {
+        first_of_level[partial] = taken;
+        if (taken + per_level[partial] > budget) {
+            partial_count = budget - taken;
+            break;
+        }
+        taken += per_level[partial];
+    }
+    const size_t region = taken + partial_count;
+    // new position of every node
+    std::vector<uint32_t> place(n);
+    std::vector<size_t> seen(deepest + 1u, 0);
+    size_t below = region;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t l = level[i];
+        const size_t rank = seen[l]++;
+        if (l < partial || (l == partial && rank < partial_count))
+            place[i] = (uint32_t)(first_of_level[l] + rank);
+        else
+            place[i] = (uint32_t)below++;
+    }
+    out.assign(n, WalkNode{});
+    for (size_t i = 0; i < n; ++i) {
+        WalkNode w = nodes[i];
+        w.skip = nodes[i].skip < n ? place[nodes[i].skip] * 32u : kRefNone;
+        if (nodes[i].leaf == kInterior) {
+            w.leaf = place[i + 1] * 32u;
+        } else {
+            const uint32_t slot = nodes[i].leaf & ~kSphereBit;
+            if (slot > kRefIndex) {
+                err = "the walk table holds 30-bit leaf slots";
+                return false;
+            }
+            w.leaf = kRefLeaf | ((nodes[i].leaf & kSphereBit) ? kRefSphere : 0u) | slot;
+        }
+        out[place[i]] = w;
+    }
+    if (region_nodes) *region_nodes = region;
+    return true;
+}
+
 } // namespace rt

@@ -41,4 +41,11 @@ using ExternalTreeBuilder = std::function<int(const BuildBox *boxes, uint32_t n,
 int build_host_scene(const rt_scene_desc *desc, HostScene &out, std::string &err, const ExternalTreeBuilder *external = nullptr,
                      uint64_t external_min_objects = 0);
 
+// The walk table (WalkNode, rt_device.h) of the pre-order table `nodes` (n entries): `out` receives the n records,
+// the first `*region_nodes` of them the nodes nearest the root, level by level and left to right within a level (so
+// that every prefix of the region is itself a treetop), at most `max_region_nodes`; the others follow in pre-order.
+// Fails (false, message in `err`) when byte offsets into the table do not fit 31 bits or a leaf slot 30 bits.
+bool build_walk_table(const Node *nodes, size_t n, size_t max_region_nodes, std::vector<WalkNode> &out, size_t *region_nodes,
+                      std::string &err);
+
 } // namespace rt
