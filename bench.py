@@ -92,9 +92,9 @@ def leg_scene(name):
 
 
 def committed_profile(name, kernel_hint, rays_per_launch):
-    """The PMC figures of profiles/r02_pmc_<leg>.json, or (None, reason) when they do not describe this build and
+    """The PMC figures of profiles/r03_pmc_<leg>.json, or (None, reason) when they do not describe this build and
     this workload: the kernel sources must hash the same and the profiled launch must have traced the same rays."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_{name}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_{name}.json")
     if not os.path.exists(path):
         return None, "no committed PMC profile"
     p = json.load(open(path))

@@ -868,6 +868,11 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     P.width = st->image_width;
     P.height = st->image_height;
     P.npix = npix;
+    // Camera rays in 8 x 8 pixel tiles where bounce 0 runs in lockstep over tables in the caches (lit teapot 7.62 -> 7.83
+    // Grays/s, 100 k soup 4.41 -> 4.85, 300 k soup 2.07 -> 2.31; the teapot seen from inside loses: 4.80 -> 4.67).  Tables in
+    // LDS and lanes from the camera ray on gain nothing from it (Cornell 25.2 -> 24.6, 10 M soup 0.655 -> 0.649).
+    const bool tiles = lanes && lanes_lockstep_first && st->image_width % 8u == 0u && st->image_height % 8u == 0u;
+    P.tiles_x = tiles ? st->image_width / 8u : 0u;
     P.max_depth = st->max_depth;
     P.mode = st->mode;
     P.seed_mix = rt::mix64(st->seed);

@@ -21,6 +21,21 @@
 
 namespace rt {
 
+#ifdef RT_LANE_STATS
+// Tuning aid (variant builds only): lane-rounds of k_paths_lanes by what the lane was doing.
+// 0 node rounds, 1 lanes stepping in them, 2 leaf rounds, 3 lanes stepping in them, 4 lanes finished (awaiting service),
+// 5 lanes without a path, 6 lanes waiting at a leaf during a node round, 7 services, 8 lanes shaded in them
+__device__ unsigned long long g_lane_stats[16];
+extern "C" __attribute__((visibility("default"))) int rt_debug_lane_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), zero, sizeof zero) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -414,6 +429,33 @@ struct StackWalk {
     }
 };
 
+// One record of the walk table for every active lane: record `at` (a byte offset) from the block's LDS copy of the
+// treetop when at < top_bytes, else through the caches (scalar base + 32-bit offset).  `lds_top` is the LDS address (byte
+// offset within the block's LDS) of the staged treetop.  Both kinds of loads are issued under their own execution
+// mask and awaited together, so a round costs the longer of the two latencies once, and the four 16-byte halves land in
+// the same two register quads (each lane is written by the one load that was issued for it).  Written in assembly
+// because the compiler turns a two-sided load into generic (flat) loads and splits them.  `nodes` must be uniform.
+__device__ __forceinline__ void load_walk_node(const float4 *__restrict__ nodes, uint32_t lds_top, uint32_t top_bytes, uint32_t at,
+                                               float4 &nlo, float4 &nhi) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f lo4, hi4;
+    unsigned long long saved;
+    const unsigned long long in_top = ballot(at < top_bytes);
+    asm volatile("s_and_saveexec_b64 %[saved], %[top]\n\t"
+                 "ds_read_b128 %[lo], %[la]\n\t"
+                 "ds_read_b128 %[hi], %[la] offset:16\n\t"
+                 "s_andn2_b64 exec, %[saved], %[top]\n\t"
+                 "global_load_dwordx4 %[lo], %[off], %[base]\n\t"
+                 "global_load_dwordx4 %[hi], %[off], %[base] offset:16\n\t"
+                 "s_mov_b64 exec, %[saved]\n\t"
+                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : [lo] "=&v"(lo4), [hi] "=&v"(hi4), [saved] "=&s"(saved)
+                 : [top] "s"(in_top), [la] "v"(at + lds_top), [off] "v"(at), [base] "s"(nodes)
+                 : "memory");
+    nlo = make_float4(lo4.x, lo4.y, lo4.z, lo4.w);
+    nhi = make_float4(hi4.x, hi4.y, hi4.z, hi4.w);
+}
+
 // The stackless pre-order walk (traverse() above) in the same begin / step form, for one lane per path over tables
 // that sit in the caches, on the walk table (WalkNode, rt_device.h): cur is the byte offset of the node to test next,
 // or kRefLeaf | slot when the node just tested was a leaf whose box is hit and its primitive test is still due (then
@@ -444,35 +486,42 @@ struct TopWalk {
             tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
         cur = resume;
     }
-    // `lds_top`: LDS address (byte offset within the block's LDS) of the staged treetop.  Lanes below the treetop read
-    // their record through the caches (scalar base + 32-bit offset), the others from LDS, in ONE round: both kinds of
-    // loads are issued under their own execution mask and awaited together, so a round costs the longer of the two
-    // latencies once, and the four 16-byte halves land in the same two register quads (each lane is written by the
-    // one load that was issued for it).  Written in assembly because the compiler turns a two-sided load into generic
-    // (flat) loads and splits them.
     __device__ __forceinline__ void step_node(const float4 *__restrict__ nodes, uint32_t lds_top, uint32_t top_bytes) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        v4f lo4, hi4;
-        unsigned long long saved;
-        const unsigned long long in_top = ballot(cur < top_bytes);
-        asm volatile("s_and_saveexec_b64 %[saved], %[top]\n\t"
-                     "ds_read_b128 %[lo], %[la]\n\t"
-                     "ds_read_b128 %[hi], %[la] offset:16\n\t"
-                     "s_andn2_b64 exec, %[saved], %[top]\n\t"
-                     "global_load_dwordx4 %[lo], %[off], %[base]\n\t"
-                     "global_load_dwordx4 %[hi], %[off], %[base] offset:16\n\t"
-                     "s_mov_b64 exec, %[saved]\n\t"
-                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : [lo] "=&v"(lo4), [hi] "=&v"(hi4), [saved] "=&s"(saved)
-                     : [top] "s"(in_top), [la] "v"(cur + lds_top), [off] "v"(cur), [base] "s"(nodes)
-                     : "memory");
-        const float4 nlo = make_float4(lo4.x, lo4.y, lo4.z, lo4.w), nhi = make_float4(hi4.x, hi4.y, hi4.z, hi4.w);
+        float4 nlo, nhi;
+        load_walk_node(nodes, lds_top, top_bytes, cur, nlo, nhi);
         const bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
         const uint32_t on_hit = f2u(nhi.w), on_miss = f2u(nhi.z);
         if (hit && (on_hit & kRefLeaf)) resume = on_miss;
         cur = hit ? on_hit : on_miss;
     }
 };
+
+// The same walk for a wave whose lanes stay together (traverse() on the walk table): a lane at a hit leaf tests its
+// primitive at once.
+__device__ __forceinline__ Closest traverse_walk(const float4 *__restrict__ nodes, uint32_t lds_top, uint32_t top_bytes,
+                                                 const float4 *__restrict__ prims, V3 o, V3 d, float tmin, float tmax) {
+    const V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    tmin = in_vgpr(tmin);
+    uint32_t cur = 0u;
+    while (cur != kRefNone) {
+        float4 nlo, nhi;
+        load_walk_node(nodes, lds_top, top_bytes, cur, nlo, nhi);
+        const bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+        const uint32_t on_hit = f2u(nhi.w), on_miss = f2u(nhi.z);
+        if (hit && (on_hit & kRefLeaf)) {
+            const uint32_t slot = on_hit & kRefIndex;
+            if (on_hit & kRefSphere)
+                sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+            else
+                tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+            cur = on_miss;
+        } else {
+            cur = hit ? on_hit : on_miss;
+        }
+    }
+    return best;
+}
 
 template <int K, int THREADS>
 __device__ __forceinline__ Closest traverse_stack(const float4 *__restrict__ chain, const float4 *__restrict__ prims,
@@ -738,6 +787,19 @@ __device__ __noinline__ bool scatter_material(const SceneDev &sc, int32_t mi, V3
 // ------------------------------------------------------------------------------------------------------
 // generate: Camera::get_ray (src/camera.rs:68-93) for every (sample, pixel) of the batch
 // ------------------------------------------------------------------------------------------------------
+// Which path the i-th camera ray of a batch belongs to.  Path slots are numbered sample by sample, row by row
+// (slot = sample_in_batch * npix + pixel); taken in that order a wave's 64 camera rays are a 64 x 1 strip of the image.
+// When both image sides are multiples of eight the rays are dealt in 8 x 8 tiles instead (P.tiles_x = width / 8): a
+// wave's rays then meet the same nodes and walk for similar lengths.  A bijection of [0, n_slots) either way, so it
+// changes which lane traces a path, never the path.
+__device__ __forceinline__ uint32_t camera_slot(const RenderParams &P, uint32_t i) {
+    if (P.tiles_x == 0u) return i;
+    const uint32_t s = i / P.npix, f = i - s * P.npix;
+    const uint32_t t = f >> 6, w = f & 63u;
+    const uint32_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+    return s * P.npix + (ty * 8u + (w >> 3)) * P.width + tx * 8u + (w & 7u);
+}
+
 // Camera::get_ray (src/camera.rs:68-93) for path `slot` of the batch; returns the draw counter after it.
 __device__ __forceinline__ uint32_t generate_ray(const RenderParams &P, uint32_t slot, V3 &origin, V3 &dir,
                                                  uint32_t &s_local, uint32_t &pixel) {
@@ -777,7 +839,8 @@ __device__ __forceinline__ uint32_t generate_ray(const RenderParams &P, uint32_t
 // NaN once beta is not finite, src/renderer.rs:48), so three flag bits carry it and radiance[slot] is written
 // exactly once, when the path ends.
 __global__ __launch_bounds__(kBlock) void k_generate(RenderParams P, PathState st, uint32_t n_slots) {
-    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n_slots; slot += gridDim.x * kBlock) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += gridDim.x * kBlock) {
+        const uint32_t slot = camera_slot(P, i);
         V3 origin, dir;
         uint32_t s_local, pixel;
         uint32_t k = generate_ray(P, slot, origin, dir, s_local, pixel);
@@ -1124,18 +1187,25 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, RenderParams P, P
 // ------------------------------------------------------------------------------------------------------
 // Six waves per SIMD: the kernel needs 81 VGPRs unconstrained, one over the 80 that let a sixth wave in.
 // STACK: 0 = the stackless walk over the 32-byte node table; K > 0 = the stack traversal over the 128-byte records
-// with K stack entries per lane in LDS (tables in device memory only).
+// with K stack entries per lane in LDS (tables in device memory only); -1 = the stackless walk over the walk table,
+// whose treetop (sc.top_bytes) the block stages in LDS.
 template <bool FIRST, bool LDS_SCENE, bool NEED_UV, bool HAS_MIX = false, int STACK = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : 6))) void k_bounce(SceneDev sc, RenderParams P, PathState st, QueueView q,
                                                    uint32_t *__restrict__ queue_out, uint32_t *__restrict__ counts_out,
                                                    uint32_t *__restrict__ early_out, StackSpill spill) {
-    static_assert(!(LDS_SCENE && STACK), "the stack traversal reads its tables from device memory");
+    static_assert(!(LDS_SCENE && STACK), "the stack traversal and the walk table read their tables from device memory");
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_out, s_early;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = nodes[0], root_hi = nodes[1]; // the root box in the table's own layout, for early misses
     if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
+    const float4 *__restrict__ walk_nodes = nullptr;
+    if constexpr (STACK < 0) {
+        walk_nodes = uniform_pointer(reinterpret_cast<const float4 *>(sc.walk_nodes));
+        const uint32_t n4 = sc.top_bytes / 16u;
+        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) s_scene[i] = walk_nodes[i];
+    }
     if (threadIdx.x == 0) {
         s_out = 0u;
         s_early = 0u;
@@ -1151,7 +1221,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
             V3 o, d, beta;
             uint32_t k, flags, depth, s_local, pixel;
             if (FIRST) {
-                slot = i;
+                slot = camera_slot(P, i);
                 k = generate_ray(P, slot, o, d, s_local, pixel);
                 beta = V3{1.0f, 1.0f, 1.0f};
                 flags = 0u;
@@ -1169,9 +1239,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                 pixel = slot - s_local * P.npix;
             }
             Closest best;
-            if constexpr (STACK != 0) {
-                best = traverse_stack<(STACK ? STACK : 1), kBlock>(reinterpret_cast<const float4 *>(sc.chain), prims, root_lo, root_hi, sc.root_ref,
-                                                                  o, d, P.z_near, P.z_far, reinterpret_cast<uint2 *>(s_scene), spill);
+            if constexpr (STACK > 0) {
+                best = traverse_stack<(STACK > 0 ? STACK : 1), kBlock>(reinterpret_cast<const float4 *>(sc.chain), prims, root_lo, root_hi, sc.root_ref,
+                                                                      o, d, P.z_near, P.z_far, reinterpret_cast<uint2 *>(s_scene), spill);
+            } else if constexpr (STACK < 0) {
+                best = traverse_walk(walk_nodes, lds_address(s_scene), sc.top_bytes, prims, o, d, P.z_near, P.z_far);
             } else {
                 uint32_t c0 = 0, c1 = 0, c2 = 0;
                 best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
@@ -1233,9 +1305,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
         if (lane == 0) quarter = atomicAdd(&s_next, 1u);
         quarter = __shfl(quarter, 0);
         if (quarter >= my_quarters) break;
-        const uint32_t slot = ((quarter >> 2) * gridDim.x + blockIdx.x) * kBlock + (quarter & 3u) * 64u + lane;
+        const uint32_t item = ((quarter >> 2) * gridDim.x + blockIdx.x) * kBlock + (quarter & 3u) * 64u + lane;
+        const uint32_t slot = item < n_slots ? camera_slot(P, item) : item;
         int alive = kPathEnded;
-        if (slot < n_slots) {
+        if (item < n_slots) {
             V3 o, d;
             uint32_t s_local, pixel;
             const uint32_t k = generate_ray(P, slot, o, d, s_local, pixel);
@@ -1360,6 +1433,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
         const uint32_t idle = n_fin + (exhausted ? 0u : n_empty);
         const uint32_t usable = 64u - (exhausted ? n_empty : 0u);
         if (n_busy == 0u || idle * RT_SERVICE_DIV >= usable) {
+#ifdef RT_LANE_STATS
+            if (lane == 0u) {
+                atomicAdd(&g_lane_stats[7], 1ull);
+                atomicAdd(&g_lane_stats[8], (unsigned long long)n_fin);
+            }
+#endif
             if (n_fin && finished) {
                 V3 l;
                 g.o = walk.o;
@@ -1401,8 +1480,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
                             have = true;
                         }
                     } else {
-                        slot = ((item / kBlock) * gridDim.x + blockIdx.x) * kBlock + (item % kBlock);
-                        if (item < my_items && slot < n_slots) {
+                        const uint32_t at = ((item / kBlock) * gridDim.x + blockIdx.x) * kBlock + (item % kBlock);
+                        if (item < my_items && at < n_slots) {
+                            slot = camera_slot(P, at);
                             g.k = generate_ray(P, slot, g.o, g.d, s_local, pixel);
                             g.beta = V3{1.0f, 1.0f, 1.0f};
                             g.flags = 0u;
@@ -1429,6 +1509,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
             // a lane without a path has cur == kRefNone, which is neither: `have` needs no look here
             const bool leaf_lane = walk.at_leaf(), node_lane = walk.at_node();
             const uint32_t n_leaf = __popcll(ballot(leaf_lane)), n_node = __popcll(ballot(node_lane));
+#ifdef RT_LANE_STATS
+            if (lane == 0u) {
+                const bool leaf_round = n_node == 0u || n_leaf * RT_LEAF_DIV >= n_node + n_leaf;
+                const uint32_t n_have = __popcll(ballot(have));
+                atomicAdd(&g_lane_stats[leaf_round ? 2 : 0], 1ull);
+                atomicAdd(&g_lane_stats[leaf_round ? 3 : 1], (unsigned long long)(leaf_round ? n_leaf : n_node));
+                atomicAdd(&g_lane_stats[4], (unsigned long long)(n_have - n_leaf - n_node));
+                atomicAdd(&g_lane_stats[5], (unsigned long long)(64u - n_have));
+                if (!leaf_round) atomicAdd(&g_lane_stats[6], (unsigned long long)n_leaf);
+            }
+#endif
             if (n_node == 0u || n_leaf * RT_LEAF_DIV >= n_node + n_leaf) {
                 if (leaf_lane) walk.step_leaf(prims);
             } else {
@@ -1734,8 +1825,16 @@ void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const 
     if (!chain) { // the stackless walk: no stack memory; LDS holds the treetop of the walk table
         if (camera_rays_in_lockstep) {
             const QueueView all{nullptr, nullptr, cap, n_slots};
+#ifdef RT_FIRST_BOUNCE_PREORDER
             auto first = has_mix ? k_bounce<true, false, true, true, 0> : need_uv ? k_bounce<true, false, true, false, 0> : k_bounce<true, false, false, false, 0>;
             hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), 0, s, sc, P, st, all, queue, counts + grid, early + grid, spill);
+#else
+            // six 256-thread blocks to a CU: 24 KB of treetop each
+            SceneDev first_sc = sc;
+            first_sc.top_bytes = sc.top_bytes < 24u * 1024u ? sc.top_bytes : 24u * 1024u;
+            auto first = has_mix ? k_bounce<true, false, true, true, -1> : need_uv ? k_bounce<true, false, true, false, -1> : k_bounce<true, false, false, false, -1>;
+            hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), first_sc.top_bytes, s, first_sc, P, st, all, queue, counts + grid, early + grid, spill);
+#endif
             if (P.max_depth < 2u) return;
         }
         LanesKernel kernel = camera_rays_in_lockstep ? walk_kernel<false>(walk_threads, waves, need_uv, has_mix)

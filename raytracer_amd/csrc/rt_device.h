@@ -176,6 +176,7 @@ struct RenderParams {
     uint32_t mode;
     uint32_t sample_base; // global index of the batch's first sample
     uint32_t batch_samples;
+    uint32_t tiles_x; // width / 8 when camera rays are dealt in 8 x 8 pixel tiles, 0 when in row order
     uint64_t seed_mix;
 };
 

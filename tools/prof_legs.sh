@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench legs (run on the GPU box): per leg one --kernel-trace --stats run and four --pmc
 # passes over `bench.py --profile-leg LEG` (three identical launches of the leg's reference workload), then
-# tools/make_pmc_json.py turns them into profiles/r02_pmc_<leg>.json + profiles/r02_<leg>_kernel_stats.csv.
+# tools/make_pmc_json.py turns them into profiles/r03_pmc_<leg>.json + profiles/r03_<leg>_kernel_stats.csv.
 # usage: tools/prof_legs.sh OUTDIR [LEG ...]
 OUT=$1; shift
 LEGS=${@:-cornell teapot teapot_lit spheres soup10m}
@@ -20,6 +20,6 @@ for leg in $LEGS; do
     timeout -s KILL 240 rocprofv3 --pmc $p --output-format csv -d "$d/pass$i" -o pmc -- python3 bench.py --profile-leg $leg > "$d/pass$i.log" 2>&1 || { echo "$leg: pass $i failed"; tail -n 5 "$d/pass$i.log"; exit 1; }
     i=$((i+1))
   done
-  python3 tools/make_pmc_json.py "$d" "$OUT/r02_pmc_$leg.json" "$OUT/r02_${leg}_kernel_stats.csv" || exit 1
+  python3 tools/make_pmc_json.py "$d" "$OUT/r03_pmc_$leg.json" "$OUT/r03_${leg}_kernel_stats.csv" || exit 1
 done
 echo done

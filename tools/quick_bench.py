@@ -52,6 +52,14 @@ def main():
               f"rays/path {st.rays_traced/st.paths:.3f} -> {st.rays_traced/st.total_ms/1e3:.1f} Mrays/s; "
               f"pipe {st.pipeline} bounce {st.bounce_ms:.2f} ({st.timed_bounce_rays/1e6:.1f}M) ext_rays {st.timed_extend_rays/1e6:.1f}M gen {st.generate_ms:.2f} ext {st.extend_ms:.2f} shade {st.shade_ms:.2f} acc {st.accumulate_ms:.2f} ms; "
               f"nodes/ray {st.node_visits/max(1,st.rays_traced):.2f} tri/ray {st.triangle_tests/max(1,st.rays_traced):.2f}")
+    if hasattr(ctx.lib, "rt_debug_lane_stats"):
+        out = (C.c_ulonglong * 16)()
+        ctx.lib.rt_debug_lane_stats(out, 1)
+        v = list(out)
+        rounds = v[0] + v[2]
+        print(f"lane stats: node rounds {v[0]} ({v[1]/max(1,v[0]):.1f} lanes), leaf rounds {v[2]} ({v[3]/max(1,v[2]):.1f} lanes); "
+              f"per round: finished {v[4]/max(1,rounds):.1f}, without path {v[5]/max(1,rounds):.1f}, waiting at leaf in node rounds "
+              f"{v[6]/max(1,v[0]):.1f}; services {v[7]} ({v[8]/max(1,v[7]):.1f} lanes shaded)")
     img /= spp
     fin = np.isfinite(img)
     print(f"nan {np.isnan(img).mean():.4f} inf {np.isinf(img).mean():.4f} mean(finite) {img[fin].mean():.5f}")
