@@ -10,6 +10,9 @@ on the device.  One ray = one closest-hit query (`world.hit`, src/renderer.rs:44
 N > 1 runs one rank per GPU: either a launcher (torch.distributed.run) has started the N ranks, or bench.py
 starts them itself as a child process.
 
+After the timed steps the run renders exactly `--total-spp` (1024) samples per pixel split over the ranks, with one
+exchange and one download, and reports that wall time next to the figure extrapolated from the steps' rate.
+
 At N = 1 the same run also times the other configurations (teapot, 485 spheres, 10 M triangle soup: `legs` in
 the JSON line), each with its own roofline, and the CPU oracle on the host cores (`cpu_baseline`).
 
@@ -41,6 +44,11 @@ SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; the chip's maximum shader cl
 # wave64 VALU instructions per second: a SIMD is 32 lanes wide, so one instruction every two cycles (the chip's
 # 157.3 TFLOP/s of vector binary32 is this rate x 64 lanes x 2 flops of a fused multiply-add)
 VALU_PEAK = SIMDS * CLOCK_HZ / 2.0
+FP32_PEAK_FLOPS = VALU_PEAK * 64 * 2  # 157.3 TFLOP/s of vector binary32
+# Algorithmic flops per test: a box test is 6 subtractions, 6 multiplications, 3 divisions (the reference recomputes
+# 1 / d per node) and 15 compares / selects = 30; a Moeller-Trumbore triangle test 45; a sphere test 28 (three dot
+# products, the discriminant, one square root, two divisions, the range compares).
+FLOPS_PER_BOX, FLOPS_PER_TRIANGLE, FLOPS_PER_SPHERE = 30, 45, 28
 # What tools/calib/valu_issue.hip sustains on the chip with 6 waves per SIMD (profiles/r02_valu_issue.txt): streams of
 # independent add/mul/fma/mov/and/xor reach 0.70-0.80 of VALU_PEAK (the clock falls to 2.05-2.2 GHz under them);
 # min/max/compare/select/shift/integer multiply/convert/div_fixup issue once per 4.2 cycles, rcp/sqrt once per 8.2.
@@ -146,7 +154,10 @@ def run_leg(name, device, launches, warmup=1, width=None, height=None, want_coun
     assert all(s.rays_traced == rays for s in stats), "identical launches must trace identical rays"
     kernel_ms = sum(s.bounce_ms + s.extend_ms + s.shade_ms + s.generate_ms for s in stats) / launches
     total_ms = sum(s.total_ms for s in stats) / launches
+    from raytracer_amd.scenes import scene_digest
+
     out = {"workload": f"{what}; {w}x{h}, depth {MAX_DEPTH}, {spp} spp per launch, progressive (gamma per sample)",
+           "scene_sha256": scene_digest(desc),  # tests/golden/scene_digests.json pins the procedural scenes
            "triangles": info.num_triangles, "spheres": info.num_spheres, "bvh_nodes": info.num_nodes, "bvh_depth": info.depth,
            "scene_bytes_in_hbm": info.device_bytes, "scene_setup_s": setup_s,
            "pipeline": PIPELINES.get(stats[0].pipeline, str(stats[0].pipeline)), "launches": launches,
@@ -187,9 +198,18 @@ def roofline_of(name, leg):
     secs = leg["render_kernel_ms_per_launch"] * 1e-3
     alg_gbs = leg["algorithmic_bytes_per_ray"] * leg["rays_per_launch"] / secs / 1e9
     hbm_bound = name == "soup10m"
+    flops_per_ray = (FLOPS_PER_BOX * leg["box_tests_per_ray"] + FLOPS_PER_TRIANGLE * leg["triangle_tests_per_ray"] +
+                     FLOPS_PER_SPHERE * leg["sphere_tests_per_ray"])
+    alg_flops = flops_per_ray * leg["rays_per_launch"] / secs
+    # the byte formula's figure against the HBM peak: for a scene served by LDS or the L2s these bytes never reach HBM
+    alg_key = "algorithmic_frac_of_hbm_peak" if hbm_bound else "algorithmic_bytes_are_lds_or_l2_traffic_ratio_to_hbm_peak"
     r = {"kernel": prof["kernel"] if prof else kernel_hint, "avg_launch_ms": leg["render_kernel_ms_per_launch"],
          "rays_per_launch": leg["rays_per_launch"], "algorithmic_bytes_per_ray": leg["algorithmic_bytes_per_ray"],
-         "algorithmic_gbs": alg_gbs, "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+         "algorithmic_gbs": alg_gbs, alg_key: alg_gbs / HBM_PEAK_GBS,
+         "algorithmic_flops_per_ray": flops_per_ray, "algorithmic_tflops": alg_flops / 1e12,
+         "algorithmic_flop_frac": alg_flops / FP32_PEAK_FLOPS,
+         "algorithmic_flop_frac_is": f"({FLOPS_PER_BOX} flop x box tests + {FLOPS_PER_TRIANGLE} x triangle tests + "
+                                     f"{FLOPS_PER_SPHERE} x sphere tests) per second over {FP32_PEAK_FLOPS / 1e12:.1f} TFLOP/s",
          "pmc": origin if prof else None, "pmc_status": "matches this build and this launch" if prof else origin}
     traffic = None
     if prof:
@@ -207,6 +227,9 @@ def roofline_of(name, leg):
         ach = prof["per_ray"]["valu_wave_instructions"] * leg["rays_per_launch"] / secs
         r.update({"bound": "valu", "achieved": ach / 1e9, "peak": VALU_PEAK / 1e9, "unit": "G wave-instructions/s",
                   "frac": ach / VALU_PEAK, "traffic": traffic,
+                  # an issued instruction counts in `frac` whatever share of its 64 lanes is masked off: this is the
+                  # share of the peak's lane-slots that did work
+                  "useful_lane_frac": ach / VALU_PEAK * prof["lane_utilisation"],
                   "peak_is": f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz / 2 cycles per wave64 VALU instruction "
                              "(= 157.3 TFLOP/s of vector binary32)",
                   "measured_issue_rates": {k: v / 1e9 for k, v in VALU_SUSTAINED.items()},
@@ -215,7 +238,7 @@ def roofline_of(name, leg):
                   "frac_at_four_cycles_per_instruction": ach / (VALU_PEAK / 2.0)})
     else:
         r.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave-instructions/s", "frac": None,
-                  "traffic": None})
+                  "useful_lane_frac": None, "traffic": None})
     r["traffic_unit"] = "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; a read request is one 128-byte line)"
     return r
 
@@ -276,6 +299,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo is for rehearsals")
     ap.add_argument("--share-device0", action="store_true",
                     help="rehearsal on a one-GPU box: every rank renders on cuda:0 (use with --backend gloo)")
+    ap.add_argument("--total-spp", type=int, default=1024,
+                    help="after the timed steps, render exactly this many samples per pixel split over the ranks, "
+                         "with one exchange and one download, and report the wall time (0 = skip)")
+    ap.add_argument("--dump-image", default=None, help="rank 0 writes the images of the run to this .npz (tests)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     args = ap.parse_args()
@@ -396,10 +423,37 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # Time to N samples per pixel, measured: the ranks split samples [0, N) of every pixel (strong scaling), each renders
+    # its block into a zeroed accumulator, ONE all-reduce adds the accumulators and rank 0 downloads the image
+    # (src/renderer.rs:105-156 is the loop this stands for).  Wall clock from fence to fence, exchange and download
+    # included, maximum over the ranks.
+    measured_s, measured_img = None, None
+    if args.total_spp > 0:
+        host_img = torch.empty(npix * 3, dtype=torch.float32, pin_memory=True)
+        begin, count = sample_range(args.total_spp, world, rank)
+        rs_total = RenderSettings(WIDTH, HEIGHT, 0, MAX_DEPTH, args.total_spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=SEED,
+                                  sample_begin=begin, sample_count=count).to_c()
+        buf = step_bufs[0]
+        fence()
+        t1 = time.perf_counter()
+        buf.zero_()
+        if count:
+            F.check(lib, lib.rt_render_device(ctx.handle, scene.handle, C.byref(cam), C.byref(rs_total),
+                                              C.c_void_p(buf.data_ptr()), None))
+        if world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            host_img.copy_(buf, non_blocking=True)
+        fence()
+        measured_s = time.perf_counter() - t1
+        if rank == 0:
+            measured_img = host_img.numpy() / np.float32(args.total_spp)
+
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, measured_s or 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        measured_s = float(t[1].item()) if measured_s is not None else None
         cnt = torch.tensor([acc["rays"], acc["paths"]], dtype=torch.int64, device=dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         rays_all, paths_all = int(cnt[0].item()), int(cnt[1].item())
@@ -409,6 +463,9 @@ def main():
     if rank == 0:
         img = (total / float(spp * world * (args.steps + args.warmup))).cpu().numpy()
         finite = np.isfinite(img)
+        if args.dump_image:
+            np.savez(args.dump_image, steps_mean=img.reshape(HEIGHT, WIDTH, 3),
+                     total_spp_mean=(measured_img if measured_img is not None else np.zeros(0, np.float32)))
         full_size = (WIDTH, HEIGHT, spp) == (1920, 1080, SPP_PER_STEP)
         scene.close()
         ctx.close()
@@ -452,6 +509,12 @@ def main():
             "mpaths_per_s": paths_all / elapsed / 1e6,
             "rays_per_path": rays_all / max(1, paths_all),
             "time_to_1024spp_s": 1024.0 * npix / (paths_all / elapsed),
+            "time_to_1024spp_is": "extrapolated from the timed steps' path rate (accumulators stay on the GPUs)",
+            f"time_to_{args.total_spp}spp_measured_s": measured_s,
+            f"time_to_{args.total_spp}spp_measured_is": (
+                f"wall clock of one render of samples [0, {args.total_spp}) of every pixel split over {n_gpus} rank(s) "
+                "(strong scaling), one all-reduce of the accumulators and the download of the image to rank 0's host "
+                "memory, fence to fence, maximum over ranks") if measured_s is not None else None,
             "pipeline": PIPELINES.get(acc["pipeline"], str(acc["pipeline"])),
             "kernel_ms_rank0": {"gpu_ms": acc["gpu_ms"], "render_kernels_ms": acc["render_ms"],
                                 "accumulate_ms": acc["accumulate_ms"]},

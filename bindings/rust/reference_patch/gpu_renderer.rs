@@ -233,25 +233,35 @@ impl GpuRenderer {
     }
 
     /// `Renderer::render_progressive(output, square_size)` (src/renderer.rs:105-156): one device call per
-    /// report interval instead of one frame per sample.
+    /// report interval instead of one frame per sample.  The running `aggregate_image` (src/renderer.rs:110) lives
+    /// on the GPU: `rt_render_device` adds every sample of the interval to it one by one in ascending sample order,
+    /// the order of `aggregate_image[idx] += ...` (src/renderer.rs:135-137), so the sums do not depend on where the
+    /// report intervals fall; each report downloads a copy.
     pub fn render_progressive(&self, mut output: ImageOutput, _square_size: usize) -> Result<()> {
         let (w, h, spp) = (self.render.image_width, self.render.image_height, self.render.samples_per_pixel);
         output.init(w, h)?;
-        let mut aggregate = vec![0.0f32; (w * h * 3) as usize];
-        let mut part = vec![0.0f32; aggregate.len()];
-        let mut done = 0;
-        while done < spp {
-            let next = (done + 1..=spp).find(|s| should_save_image(*s, spp)).unwrap();
-            let st = self.settings(sys::RT_MODE_GAMMA_PER_SAMPLE, done, next - done);
-            check(unsafe { sys::rt_render(self.ctx, self.scene, &self.camera, &st, part.as_mut_ptr(), ptr::null_mut()) })?;
-            for (a, p) in aggregate.iter_mut().zip(&part) {
-                *a += *p;
+        let len = (w * h * 3) as usize;
+        let mut d_aggregate: *mut f32 = ptr::null_mut();
+        check(unsafe { sys::rt_accum_create(self.ctx, w, h, &mut d_aggregate) })?;
+        let mut aggregate = vec![0.0f32; len];
+        let mut run = || -> Result<()> {
+            let mut done = 0;
+            while done < spp {
+                let next = (done + 1..=spp).find(|s| should_save_image(*s, spp)).unwrap();
+                let st = self.settings(sys::RT_MODE_GAMMA_PER_SAMPLE, done, next - done);
+                check(unsafe {
+                    sys::rt_render_device(self.ctx, self.scene, &self.camera, &st, d_aggregate, ptr::null_mut())
+                })?;
+                check(unsafe { sys::rt_accum_download(self.ctx, d_aggregate, len, aggregate.as_mut_ptr()) })?;
+                done = next;
+                let scale = 1.0 / done as f32;
+                output.write(aggregate.iter().map(|c| c * scale).collect(), w, h)?;
             }
-            done = next;
-            let scale = 1.0 / done as f32;
-            output.write(aggregate.iter().map(|c| c * scale).collect(), w, h)?;
-        }
-        Ok(())
+            Ok(())
+        };
+        let result = run();
+        unsafe { sys::rt_accum_destroy(self.ctx, d_aggregate) };
+        result
     }
 }
 

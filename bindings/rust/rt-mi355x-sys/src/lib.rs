@@ -220,6 +220,10 @@ extern "C" {
                      accum: *mut f32, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_device(ctx: *mut rt_context, scene: *const rt_scene, camera: *const rt_camera,
                             settings: *const rt_settings, d_accum: *mut f32, stats: *mut rt_stats) -> c_int;
+    /// A zeroed accumulator of 3 * width * height floats in device memory (the `d_accum` of `rt_render_device`).
+    pub fn rt_accum_create(ctx: *mut rt_context, width: u32, height: u32, d_accum: *mut *mut f32) -> c_int;
+    pub fn rt_accum_download(ctx: *mut rt_context, d_accum: *const f32, count: usize, host: *mut f32) -> c_int;
+    pub fn rt_accum_destroy(ctx: *mut rt_context, d_accum: *mut f32) -> c_int;
     pub fn rt_allreduce_sum(ctxs: *const *mut rt_context, n_gpus: c_int, d_accum: *const *mut f32, count: usize) -> c_int;
     pub fn rt_render_node(ctxs: *const *mut rt_context, scenes: *const *const rt_scene, n_gpus: c_int,
                           camera: *const rt_camera, settings: *const rt_settings, accum: *mut f32) -> c_int;

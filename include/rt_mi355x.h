@@ -364,6 +364,19 @@ int rt_render(rt_context *ctx, const rt_scene *scene, const rt_camera *camera, c
 int rt_render_device(rt_context *ctx, const rt_scene *scene, const rt_camera *camera,
                      const rt_settings *settings, float *d_accum, rt_stats *stats);
 
+/* The running `aggregate_image` of `Renderer::render_progressive` (src/renderer.rs:110: `vec![0.0; len]`) as a buffer
+ * in device memory, for hosts that have no device allocator of their own: 3 * width * height floats, zeroed,
+ * on the context's device; pass it to rt_render_device as `d_accum`. */
+int rt_accum_create(rt_context *ctx, uint32_t width, uint32_t height, float **d_accum);
+
+/* Copies such a buffer (or any device buffer of `count` floats rt_render_device has written) to `host` after the
+ * work enqueued on the context's stream so far, and waits for the copy: what `aggregate_image.iter()` reads when a
+ * frame is reported (src/renderer.rs:138-147).  The device buffer keeps its contents. */
+int rt_accum_download(rt_context *ctx, const float *d_accum, size_t count, float *host);
+
+/* Frees a buffer of rt_accum_create (after the work enqueued on the context's stream). */
+int rt_accum_destroy(rt_context *ctx, float *d_accum);
+
 /* Sums the accumulators of a sample-sharded render across GPUs, in place: afterwards every `d_accum[i]`
  * (device memory of `ctxs[i]`'s device, `count` floats) holds the element-wise sum over all `n_gpus` buffers.
  * This is the one exchange step of `aggregate_image += sample` (src/renderer.rs:135-137) when the samples of a

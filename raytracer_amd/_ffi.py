@@ -149,6 +149,9 @@ EXPORTS = {
     "rt_image_free": (None, [C.POINTER(C.c_uint8)]),
     "rt_render_device": (C.c_int, [_vp, _vp, C.POINTER(rt_camera), C.POINTER(rt_settings), _vp,
                                    C.POINTER(rt_stats)]),
+    "rt_accum_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "rt_accum_download": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "rt_accum_destroy": (C.c_int, [_vp, _vp]),
     "rt_allreduce_sum": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_size_t]),
     "rt_render_node": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.c_int, C.POINTER(rt_camera),
                                  C.POINTER(rt_settings), _vp]),

@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include "rt_device.h"
 #include "rt_math.h"
+#include "sample_split.h"
 #include "scene_build.h"
 
 #define RT_API extern "C" __attribute__((visibility("default")))
@@ -1014,6 +1015,45 @@ RT_API int rt_render(rt_context *c, const rt_scene *s, const rt_camera *cam, con
     return RT_OK;
 }
 
+RT_API int rt_accum_create(rt_context *c, uint32_t width, uint32_t height, float **d_accum) {
+    if (!c || !d_accum) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_accum_create: null argument");
+    *d_accum = nullptr;
+    if (width == 0 || height == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "image size must be non-zero");
+    if ((uint64_t)width * height > (1ull << 26)) return set_error(RT_ERR_INVALID_ARGUMENT, "image larger than 2^26 pixels");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return set_error(RT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    if (hipMemsetAsync(p, 0, bytes, c->stream) != hipSuccess) {
+        (void)hipFree(p);
+        return set_error(RT_ERR_DEVICE, "clearing the accumulator failed");
+    }
+    *d_accum = static_cast<float *>(p);
+    return RT_OK;
+}
+
+RT_API int rt_accum_download(rt_context *c, const float *d_accum, size_t count, float *host) {
+    if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_accum_download: null context");
+    if (count == 0) return RT_OK;
+    if (!d_accum || !host) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_accum_download: null buffer");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return set_error(RT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+    HIP_TRY(hipMemcpyAsync(host, d_accum, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+RT_API int rt_accum_destroy(rt_context *c, float *d_accum) {
+    if (!c) return set_error(RT_ERR_INVALID_ARGUMENT, "rt_accum_destroy: null context");
+    if (!d_accum) return RT_OK;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return set_error(RT_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d_accum));
+    return RT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // rt_allreduce_sum: RCCL all-reduce over the contexts of one process.  RCCL is bound with dlopen so that the
 // library (and single-GPU users) do not depend on it at load time.
@@ -1129,9 +1169,7 @@ RT_API int rt_render_node(rt_context *const *ctxs, const rt_scene *const *scenes
     }
     const size_t n = (size_t)st->image_width * st->image_height * 3;
     const uint32_t total = st->sample_count ? st->sample_count : st->samples_per_pixel;
-    const uint32_t base = total / (uint32_t)n_gpus, extra = total % (uint32_t)n_gpus;
     std::vector<float *> bufs((size_t)n_gpus);
-    uint32_t begin = st->sample_begin;
     for (int i = 0; i < n_gpus; ++i) { // enqueue every GPU's share; nothing here waits for a device
         rt_context *c = ctxs[i];
         DeviceGuard guard(c->device);
@@ -1140,9 +1178,7 @@ RT_API int rt_render_node(rt_context *const *ctxs, const rt_scene *const *scenes
         bufs[(size_t)i] = c->accum.ptr;
         HIP_TRY(hipMemsetAsync(c->accum.ptr, 0, n * sizeof(float), c->stream));
         rt_settings part = *st;
-        part.sample_begin = begin;
-        part.sample_count = base + ((uint32_t)i < extra ? 1u : 0u);
-        begin += part.sample_count;
+        rt::sample_block(st->sample_begin, total, (uint32_t)n_gpus, (uint32_t)i, &part.sample_begin, &part.sample_count);
         if (part.sample_count == 0) continue; // more GPUs than samples: this one contributes zeros
         if (int rc = rt_render_device(c, scenes[i], cam, &part, c->accum.ptr, nullptr)) return rc;
     }

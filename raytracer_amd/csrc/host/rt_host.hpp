@@ -213,26 +213,32 @@ class Renderer {
     void render_progressive(const std::function<void(const std::vector<float> &, uint32_t, uint32_t, uint32_t)> &output,
                             size_t /*square_size*/ = 16, rt_stats *total = nullptr) const {
         const uint32_t w = render_.image_width, h = render_.image_height, spp = render_.samples_per_pixel;
-        std::vector<float> aggregate((size_t)w * h * 3, 0.0f), part(aggregate.size());
+        // The running aggregate_image (src/renderer.rs:110) lives on the GPU: rt_render_device adds the samples of a
+        // report interval to it one by one in ascending order, the order of src/renderer.rs:135-137, so the sums do
+        // not depend on where the intervals fall; each report downloads a copy.
+        std::vector<float> aggregate((size_t)w * h * 3, 0.0f), image(aggregate.size());
+        float *d_aggregate = nullptr;
+        check(rt_accum_create(ctx_.get(), w, h, &d_aggregate));
+        struct Release {
+            rt_context *ctx;
+            float *p;
+            ~Release() { (void)rt_accum_destroy(ctx, p); }
+        } release{ctx_.get(), d_aggregate};
         uint32_t done = 0;
         while (done < spp) {
             uint32_t next = done + 1;
             while (!should_save_image(next, spp)) ++next;
             rt_settings st = settings(RT_MODE_GAMMA_PER_SAMPLE, done, next - done);
             rt_stats s;
-            check(rt_render(ctx_.get(), scene_.get(), &camera_, &st, part.data(), &s));
+            check(rt_render_device(ctx_.get(), scene_.get(), &camera_, &st, d_aggregate, &s));
+            check(rt_accum_download(ctx_.get(), d_aggregate, aggregate.size(), aggregate.data()));
             if (total) {
                 total->rays_traced += s.rays_traced;
                 total->paths += s.paths;
                 total->total_ms += s.total_ms;
             }
-            // Adding a block of samples to the running sum is not the same float operation order as adding them
-            // one by one unless the block starts from the running sum; rt_render_device does exactly that on the
-            // GPU.  With host buffers the first block is exact and later blocks differ in the last bits only.
-            for (size_t i = 0; i < aggregate.size(); ++i) aggregate[i] += part[i];
             done = next;
             const float sample_scale = 1.0f / (float)done;
-            std::vector<float> image(aggregate.size());
             for (size_t i = 0; i < aggregate.size(); ++i) image[i] = aggregate[i] * sample_scale;
             output(image, w, h, done);
         }

@@ -117,8 +117,11 @@ def pixels_to_rgb8(pixels: np.ndarray) -> np.ndarray:
     """`pixels_to_image` (src/renderer.rs:173-176): Rgb32F -> Rgb8 as the `image` crate converts it,
     round(clamp(c, 0, 1) * 255); NaN becomes 0."""
     p = np.nan_to_num(np.asarray(pixels, dtype=np.float32), nan=0.0, posinf=1.0, neginf=0.0)
-    # Rust's f32::round rounds halves away from zero (np.rint would round them to even)
-    return np.floor(np.clip(p, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    # Rust's f32::round rounds halves away from zero (np.rint would round them to even).  The product is binary32 as in
+    # the reference; the half is added in binary64, where the sum is exact (in binary32 the largest value below 0.5
+    # plus 0.5 rounds up to 1).
+    scaled = np.clip(p, 0.0, 1.0) * np.float32(255.0)
+    return np.floor(scaled.astype(np.float64) + 0.5).astype(np.uint8)
 
 
 class Renderer:

@@ -38,6 +38,19 @@ class SplitMix64:
         return float(f32(lo) + f32(hi - lo) * f32(self.unit()))
 
 
+def splitmix64_units(seed: int, first: int, count: int) -> np.ndarray:
+    """Values first .. first + count - 1 of SplitMix64(seed)'s `unit()` stream (value k is a function of seed and k
+    alone: the state after k + 1 increments, finalised), computed array-wise.  Depends on nothing but 64-bit integer
+    arithmetic, so the scenes built from it are the same on every machine and under every numpy."""
+    k = np.arange(first + 1, first + count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & _MASK) + k * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return (z >> np.uint64(40)).astype(np.float32) * f32(1.0 / 16777216.0)
+
+
 def rtiow_final_scene(seed: int = 0x5EED):
     """The "final scene" of Ray Tracing in One Weekend: a ground sphere, a 22 x 22 grid of small random
     spheres (80 % lambertian, 15 % metal, 5 % glass) and three large ones.  Returns (scene, camera settings).
@@ -75,22 +88,25 @@ def rtiow_final_scene(seed: int = 0x5EED):
 def triangle_soup(n_triangles: int = 10_000_000, seed: int = 0xC0FFEE, emissive_fraction: float = 0.001):
     """`n_triangles` small triangles with centroids uniform in [-1, 1]^3 and vertices within +-0.005 of the
     centroid; Lambertian albedo 0.8 except a fraction of emitters of strength 50.  No normals and no
-    texture coordinates, so every hit takes the geometric-normal path.  Returns (scene, camera settings)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+    texture coordinates, so every hit takes the geometric-normal path.  Generator: SplitMix64(seed), twelve values per
+    triangle, so the first k triangles do not depend on how many follow.  Returns (scene, camera settings)."""
     sc = SceneDescription()
     n_emit = max(1, int(round(n_triangles * emissive_fraction))) if emissive_fraction > 0 else 0
     n_diff = n_triangles - n_emit
     diffuse = sc.lambertian((0.8, 0.8, 0.8))
     emit = sc.diffuse_light((1.0, 1.0, 1.0), 50.0)
+    drawn = [0]  # triangles generated so far: triangle t takes values 12 t .. 12 t + 11 of the SplitMix64(seed) stream
 
     def mesh(n, material):
         chunk = 1 << 20
         pos = np.empty((n * 3, 3), dtype=f32)
         for s in range(0, n, chunk):
             e = min(n, s + chunk)
-            c = rng.random((e - s, 1, 3), dtype=np.float32) * f32(2.0) - f32(1.0)
-            off = rng.random((e - s, 3, 3), dtype=np.float32) * f32(0.01) - f32(0.005)
+            u = splitmix64_units(seed, 12 * (drawn[0] + s), 12 * (e - s)).reshape(e - s, 4, 3)
+            c = u[:, :1, :] * f32(2.0) - f32(1.0)          # centroid, uniform in [-1, 1]^3
+            off = u[:, 1:, :] * f32(0.01) - f32(0.005)     # the three vertices, within +-0.005 of it
             pos[3 * s:3 * e] = (c + off).reshape(-1, 3)
+        drawn[0] += n
         idx = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
         return TriangleMesh(pos, idx, np.zeros((0, 3), f32), np.zeros((0, 2), f32), material)
 
@@ -102,6 +118,41 @@ def triangle_soup(n_triangles: int = 10_000_000, seed: int = 0xC0FFEE, emissive_
     cam = CameraSettings(None, float(f32(0.691111147403717)), float(f32(0.1)), 1000.0, tr, 10.0, 0.0)
     sc.cameras.append(cam)
     return sc, cam
+
+
+def scene_digest(sc: SceneDescription, max_triangles: int | None = None) -> str:
+    """sha256 over everything a render of `sc` depends on: vertex positions, indices, normals, texture coordinates and
+    material of every mesh (only the first `max_triangles` triangles of the scene when given), spheres, materials,
+    textures (image texels included).  Floats enter as their binary32 bytes."""
+    import hashlib
+
+    h = hashlib.sha256()
+
+    def put(a, dtype):
+        h.update(np.ascontiguousarray(np.asarray(a, dtype=dtype)).tobytes())
+
+    left = max_triangles
+    for m in sc.meshes:
+        n = len(m.indices) if left is None else min(left, len(m.indices))
+        idx = np.asarray(m.indices[:n], dtype=np.uint32)
+        put(idx, np.uint32)
+        if left is None:
+            put(m.positions, f32), put(m.normals, f32), put(m.uvs, f32)
+        else:  # the vertices those triangles name, in the order they name them
+            put(np.asarray(m.positions, f32)[idx.reshape(-1)], f32)
+            left -= n
+        put([m.material], np.int32)
+        if left == 0:
+            break
+    for sp in sc.spheres:
+        put(list(sp.center) + [sp.radius], f32), put([sp.material], np.int32)
+    for m in sc.materials:
+        put([m.kind, m.texture, m.left, m.right], np.int32), put([m.param], f32)
+    for t in sc.textures:
+        put([t.kind, t.even, t.odd], np.int32), put(list(t.rgb) + [t.inv_scale], f32)
+        if t.image is not None:
+            put(t.image.shape, np.int64), put(t.image, np.uint8)
+    return h.hexdigest()
 
 
 def lit_teapot(teapot: SceneDescription):

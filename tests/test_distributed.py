@@ -29,6 +29,28 @@ def test_sample_range_partitions_exactly():
         sample_range(8, 2, 2)
 
 
+def test_node_split_in_the_library_equals_sample_range(tmp_path):
+    """rt_render_node splits a render's samples among its GPUs with rt::sample_block (csrc/sample_split.h).  The native
+    check asserts contiguous, disjoint, covering blocks of near-equal length for 1, 2, 3 and 8 GPUs and 0, 1, 7, 8 and 4096
+    samples (more GPUs than samples included); its output must be sample_range's blocks, shifted by the first sample."""
+    import subprocess
+
+    exe = str(tmp_path / "sample_split_check")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "raytracer_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "sample_split_check.cpp"), "-o", exe], check=True)
+    lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(lines) == 4 * 5 * 3
+    for line in lines:
+        head, blocks = line.split(":")
+        n, total, begin = (int(v) for v in head.split())
+        got = [int(v) for v in blocks.split()]
+        want = []
+        for r in range(n):
+            b, c = sample_range(total, n, r)
+            want += [begin + b, c]
+        assert got == want, line
+
+
 def _oracle_range_renderer():
     from oracle import binding as ob
     from raytracer_amd import RenderSettings, _ffi as F, load_from_gltf

@@ -628,6 +628,30 @@ def test_render_progressive_reports(gpu_ctx, cornell):
     assert img8.dtype == np.uint8 and img8.shape == (h, w, 3)
 
 
+def test_device_accumulator_helpers(gpu_ctx, cornell):
+    """rt_accum_create / rt_accum_download / rt_accum_destroy: the running aggregate of render_progressive for hosts
+    without a device allocator (the Rust patch, the C++ host).  Two calls over consecutive sample ranges into one
+    accumulator give, bit for bit, the oracle's sums over the whole range, whatever the split."""
+    lib = gpu_ctx.lib
+    w, h, spp = 40, 24, 7
+    cam = camera_from_settings(cornell.camera(0), w, h)
+    scene, oracle = both(gpu_ctx, cornell)
+    want, _ = oracle.render(cam, RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=11), threads=8)
+    for split in (1, 3, 6):
+        d = C.c_void_p()
+        F.check(lib, lib.rt_accum_create(gpu_ctx.handle, w, h, C.byref(d)))
+        for begin, count in ((0, split), (split, spp - split)):
+            rs = RenderSettings(w, h, 0, 50, spp, mode=F.RT_MODE_GAMMA_PER_SAMPLE, seed=11, sample_begin=begin,
+                                sample_count=count).to_c()
+            F.check(lib, lib.rt_render_device(gpu_ctx.handle, scene.handle, C.byref(cam), C.byref(rs), d, None))
+        got = np.zeros((h, w, 3), np.float32)
+        F.check(lib, lib.rt_accum_download(gpu_ctx.handle, d, got.size, got.ctypes.data))
+        F.check(lib, lib.rt_accum_destroy(gpu_ctx.handle, d))
+        assert bits_equal(got, want).all(), split
+    assert lib.rt_accum_create(gpu_ctx.handle, 0, 4, C.byref(C.c_void_p())) == F.RT_ERR_INVALID_ARGUMENT
+    assert lib.rt_accum_destroy(gpu_ctx.handle, None) == F.RT_OK
+
+
 def test_render_edge_cases(gpu_ctx, cornell):
     scene, oracle = both(gpu_ctx, cornell)
     for (w, h, depth, spp) in ((1, 1, 50, 3), (7, 3, 1, 2), (5, 5, 0, 2), (33, 17, 2, 1), (257, 1, 50, 2)):
@@ -918,10 +942,14 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--width", "320", "--height", "180", "--spp-per-step", "4"]
+    size = ["--no-cpu-baseline", "--width", "320", "--height", "180", "--spp-per-step", "4", "--total-spp", "16"]
+    common = ["--steps", "2", "--warmup", "1"] + size
+    # two ranks x 2 steps x 4 spp and one rank x 4 steps x 4 spp both render samples [0, 16) of every pixel
+    two_npz, one_npz = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--backend", "gloo", "--share-device0"] + common,
+                          "--gpus", "2", "--backend", "gloo", "--share-device0", "--steps", "2", "--warmup", "0",
+                          "--dump-image", two_npz] + size,
                          capture_output=True, text=True, timeout=280, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
     # without a launcher bench.py starts the ranks itself; a launcher whose rank count contradicts --gpus is refused
@@ -934,16 +962,29 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"] + common, capture_output=True, text=True,
                          timeout=120, cwd=root, env={**env, "WORLD_SIZE": "2", "RANK": "0"})
     assert bad.returncode != 0 and "--gpus 4" in bad.stderr
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "0",
+                          "--dump-image", one_npz] + size,
                          capture_output=True, text=True, timeout=280, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j2["ranks_in_process_group"] == 2 and j2["scaling"] == "weak" and j2["config"]["allreduce_floats_per_step"] == 320 * 180 * 3
     assert j1["n_gpus"] == 1 and j1["value"] > 0 and j2["value"] > 0
-    # two ranks x 4 spp x 3 steps cover samples 0..23; one rank covers 0..11: different sample sets, so compare
-    # only statistics here (the bit-level sharding identity is tested in test_batching_and_sample_ranges...)
-    assert abs(j1["rays_per_path"] - j2["rays_per_path"]) < 0.02
-    assert abs(j1["image_check"]["finite_mean"] - j2["image_check"]["finite_mean"]) < 0.02
+    assert j1["time_to_16spp_measured_s"] > 0 and j2["time_to_16spp_measured_s"] > 0
+    # Same sample set, so the two-rank image is the one-rank image up to the association of the float additions:
+    # through the timed steps (double-buffered asynchronous all-reduce per step) and through the measured
+    # time-to-N-spp render (one exchange).  Infinite pixels (pdf = 0 bounces that met the light) and NaNs coincide.
+    i1, i2 = np.load(one_npz), np.load(two_npz)
+    for key in ("steps_mean", "total_spp_mean"):
+        a, b = i1[key].reshape(-1), i2[key].reshape(-1)
+        assert a.size == 320 * 180 * 3 and a.shape == b.shape
+        assert np.array_equal(np.isinf(a), np.isinf(b)) and np.array_equal(np.isnan(a), np.isnan(b)), key
+        fin = np.isfinite(a)
+        assert fin.mean() > 0.9
+        # sums of non-negative terms: no cancellation, so a few units in the last place; tolerance 2e-6 relative
+        rel = np.abs(a[fin] - b[fin]) / np.maximum(np.abs(a[fin]), 1e-3)
+        assert rel.max() <= 2e-6, (key, rel.max())
+    assert np.abs(i1["steps_mean"].reshape(-1)[np.isfinite(i1["steps_mean"].reshape(-1))]).max() > 0.1
+    assert abs(j1["rays_per_path"] - j2["rays_per_path"]) < 1e-9
     assert j1["roofline"]["algorithmic_gbs"] > 0 and j1["roofline"]["bound"] == "valu" and "cpu_baseline" not in j2
     assert j1["roofline"]["pmc"] is None and j1["roofline"]["traffic"] is None  # no profile speaks for a rehearsal size

@@ -196,6 +196,11 @@ def test_rgb8_rounds_halves_away_from_zero_in_both_host_layers():
     assert exact.sum() > 20 and (k[exact] % 2 == 0).any()  # even k is where round-half-to-even would differ
     want = (k[exact] + 1).astype(np.uint8)
     assert np.array_equal(pixels_to_rgb8(c[exact]), want)
+    # products just below k + 0.5 round down: in binary32 the largest value below 0.5, plus 0.5, would round up to 1
+    below = np.nextafter(np.float32(0.5), np.float32(0.0)) / np.float32(255.0)
+    assert below * np.float32(255.0) < np.float32(0.5) and pixels_to_rgb8(np.array([below], np.float32))[0] == 0
+    c_extra = np.concatenate([c[exact], np.array([below], np.float32)])
+    want_extra = np.concatenate([want, np.array([0], np.uint8)])
     src = r"""
 #include "raytracer_amd/csrc/host/rt_host.hpp"
 int main() { std::vector<float> px; float f; while (fread(&f, 4, 1, stdin) == 1) px.push_back(f);
@@ -206,8 +211,8 @@ int main() { std::vector<float> px; float f; while (fread(&f, 4, 1, stdin) == 1)
         open(cpp, "w").write(src)
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", ROOT, cpp, "-o", exe, "-L", os.path.dirname(F.LIB_PATH),
                                "-lrt_mi355x", "-lz", "-Wl,-rpath," + os.path.dirname(F.LIB_PATH)])
-        out = subprocess.run([exe], input=c[exact].tobytes(), capture_output=True, check=True).stdout
-    assert np.array_equal(np.frombuffer(out, dtype=np.uint8), want)
+        out = subprocess.run([exe], input=c_extra.tobytes(), capture_output=True, check=True).stdout
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint8), want_extra)
 
 
 def test_render_settings_defaults_match_cli():
@@ -545,3 +550,27 @@ def test_rust_binding_declares_every_entry_point():
         assert m, f"{name} missing from the Rust binding"
         rust_fields = re.findall(r"pub ([a-z_0-9]+):", m.group(1))
         assert c_fields == rust_fields, (name, c_fields, rust_fields)
+
+
+def test_benchmark_scenes_are_pinned():
+    """The procedural benchmark scenes (the 485 spheres, the triangle soups, the lit teapot) and the two glTF assets hash
+    to the digests committed in tests/golden/scene_digests.json (made by tests/golden/make_scene_digests.py): the
+    workloads behind the bench legs cannot drift with the installed numpy or an edit of the generators.  The soup draws
+    from SplitMix64 twelve values per triangle, so its first million triangles do not depend on the scene's size."""
+    import json
+
+    from raytracer_amd.scenes import SplitMix64, splitmix64_units
+
+    sys_path = os.path.join(ROOT, "tests", "golden")
+    want = json.load(open(os.path.join(sys_path, "scene_digests.json")))
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_scene_digests", os.path.join(sys_path, "make_scene_digests.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.digests() == want
+    # the array-wise generator is the sequential one
+    rng = SplitMix64(0xC0FFEE)
+    seq = np.array([rng.unit() for _ in range(300)], np.float32)
+    assert np.array_equal(splitmix64_units(0xC0FFEE, 0, 300), seq)
+    assert np.array_equal(splitmix64_units(0xC0FFEE, 123, 100), seq[123:223])
