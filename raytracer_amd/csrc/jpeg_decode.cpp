@@ -357,7 +357,11 @@ struct Decoder {
         if (n_comp == 4) return fail("four-component (CMYK / YCCK) files are not supported");
         if (n_comp != 1 && n_comp != 3) return fail("bad component count");
         if (end - at < 6 + 3 * (size_t)n_comp) return fail("short frame header");
-        if ((uint64_t)width * (uint64_t)height > (1ull << 28)) return fail("image too large");
+        // Planes are allocated from these two numbers before a single coded byte is looked at: refuse sizes a texture
+        // does not have (64 M pixels) and sizes the file cannot hold (a block of 64 pixels takes at least one coded
+        // bit per component, so more than 512 pixels per byte of file is not a picture but a header).
+        if ((uint64_t)width * (uint64_t)height > (1ull << 26)) return fail("image too large");
+        if ((uint64_t)width * (uint64_t)height > 512ull * (uint64_t)n + 65536ull) return fail("image size implausible for the size of the file");
         progressive = marker == 0xC2;
         for (int i = 0; i < n_comp; ++i) {
             Component &c = comp[i];

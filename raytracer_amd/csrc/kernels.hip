@@ -247,8 +247,11 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
 // lines fetched per ray is what bounds a scene read from HBM.
 //
 // The stack: the K most recent entries live in LDS (entry e of a thread at lds[(e % K) * THREADS]), older ones
-// are moved to `spill` in device memory and come back when the LDS part runs empty.  A step descends two levels and leaves at most three entries
-// behind, so fewer than 1.5 * depth + 2 entries exist at a time (the spill area has room for 2 * depth + 2).
+// are moved to `spill` in device memory and come back when the LDS part runs empty.  K must be a power of two (the
+// ring is indexed with `& (K - 1)`) and K * THREADS * 8 bytes of LDS per block must leave room for the blocks a CU is to
+// hold.  A step descends one or two levels and leaves at most two entries behind per level it descends (an L that is
+// not held plus a held (RL, RR) pair: two entries for one level), so at most 2 * depth entries exist at a time; the spill
+// area has room for 2 * depth + 2.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void slab_pair(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, V3 o, V3 inv,
                                           float tmin, float &E, float &X) {
@@ -271,6 +274,7 @@ __device__ __forceinline__ void slab_pair(float xlo, float xhi, float ylo, float
 
 template <int K, int THREADS>
 struct LaneStack {
+    static_assert(K > 0 && (K & (K - 1)) == 0, "the LDS part of the stack is a ring indexed with & (K - 1)");
     uint2 *lds;    // this thread's column of the block's LDS stack area
     uint2 *spill;  // this thread's column of the spill area
     uint32_t stride;

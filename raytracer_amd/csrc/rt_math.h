@@ -67,6 +67,10 @@ RT_HD float u2f(uint32_t u) {
 // coefficient table; an exhaustive host-side comparison over every binary32 in [-1, 1] (the only range the
 // sampler produces) matches glibc 2.35 bit for bit, with and without fused multiply-add.  Arguments outside
 // [-1, 1] are not supported.
+// Provenance: algorithm and coefficients of sysdeps/ieee754/flt-32/{s_sinf.c, s_cosf.c, s_sincosf.h,
+// s_sincosf_data.c} of the GNU C Library (contributed by Arm Ltd., "Optimized Routines"; Copyright (C) 2018-2022 Free
+// Software Foundation, Inc.; GNU Lesser General Public License v2.1 or later; the same routines are published by Arm
+// under the MIT licence).  Written out again here, not copied; the numeric constants are theirs.
 // ------------------------------------------------------------------------------------------------------
 namespace sincos_detail {
 constexpr double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
@@ -135,6 +139,10 @@ RT_HD float cos_unit(float y) {
 // break points and an 11-term polynomial).  This is a restatement of that published algorithm and its
 // coefficient tables in binary32 arithmetic, one IEEE operation per source operation; a host-side comparison
 // with glibc 2.35 (every binary32 for acosf and atanf, 10^9 argument pairs for atan2f) matches bit for bit.
+// Provenance: algorithm and coefficients of sysdeps/ieee754/flt-32/{e_acosf.c, s_atanf.c, e_atan2f.c} of the GNU C
+// Library, which are the FreeBSD / fdlibm binary32 routines ("Copyright (C) 1993 by Sun Microsystems, Inc.  All rights
+// reserved.  Developed at SunPro, a Sun Microsystems, Inc. business.  Permission to use, copy, modify, and distribute this
+// software is freely granted, provided that this notice is preserved.").  Written out again here; the constants are theirs.
 // ------------------------------------------------------------------------------------------------------
 namespace invtrig_detail {
 RT_HD float asin_ratio(float z) {
