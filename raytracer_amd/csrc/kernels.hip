@@ -97,8 +97,67 @@ __device__ __forceinline__ float min_raw(float a, float b) {
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// The three-operand forms: max(max(a, b), c) / min(min(a, b), c) with the same treatment of NaNs, in one instruction.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
-__device__ __forceinline__ bool box_hit(float4 a, float4 b, V3 o, V3 inv, float lo, float hi) {
+// A ray as the slab test wants it: per axis the origin twice (subtracted from the low and from the high plane) and the
+// reciprocal of the direction.
+//
+// Aabb::hit orders an axis' two distances with `t0 < t1` and narrows [lo, hi] by compare-and-assign.  For ordered
+// operands that is lo = max(lo, min(t0, t1)), hi = min(hi, max(t0, t1)), which v_min_f32 / v_max_f32 compute in two
+// instructions instead of a compare and two selects (the sign of a zero may differ, which no later comparison sees).
+// The two forms part only when exactly ONE of t0, t1 is a NaN (the hardware min / max then return the other operand
+// for both, compare-and-assign leaves one bound alone).  With plane - origin finite (any scene whose coordinates stay
+// below 1.7e38 in magnitude) a lone NaN is 0 * inf: the direction component is a zero and the origin lies exactly on
+// one of the two planes.  For +0 both forms reject the box.  For -0 they differ: compare-and-assign passes the axis
+// iff low <= origin <= high (planes included), min / max would reject an origin on a plane.  Such rays are common (the
+// diffuse sampler's degenerate samples have z = 0, negated for half of them), so they are not left to a fallback:
+// for an axis whose direction is -0 the ray is stored with the reciprocal +inf and the origin replaced by the next
+// binary32 above it for the low plane and the next below it for the high plane.  Then low - up(origin) is negative
+// exactly when low <= origin, high - down(origin) positive exactly when origin <= high, and the min / max form with
+// +inf passes the axis for exactly the origins compare-and-assign passes with -inf, and rejects the box for all others
+// (origins one step outside give 0 * inf = NaN on one side and the rejecting infinity on the other).  NaN and infinite
+// origins behave as before (up(+inf) = +inf, down(-inf) = -inf, NaN stays NaN).
+struct Slabs {
+    v2f ox, oy, oz;
+    V3 inv;
+};
+
+__device__ __forceinline__ float next_up(float x) { // the next binary32 towards +inf; NaN and +inf stay
+    const uint32_t u = f2u(x);
+    if (x != x || u == 0x7F800000u) return x;
+    if ((u << 1) == 0u) return u2f(1u);
+    return u2f((u >> 31) ? u - 1u : u + 1u);
+}
+__device__ __forceinline__ float next_down(float x) { return -next_up(-x); }
+
+// (The substitution is needed by few rays, and hardly ever on x or y; a wave skips an axis none of its lanes needs.)
+__device__ __forceinline__ Slabs make_slabs(V3 o, V3 d) {
+    Slabs s;
+    s.inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    s.ox = v2f{o.x, o.x};
+    s.oy = v2f{o.y, o.y};
+    s.oz = v2f{o.z, o.z};
+    const float inf = __builtin_inff();
+    const bool nx = f2u(d.x) == 0x80000000u, ny = f2u(d.y) == 0x80000000u, nz = f2u(d.z) == 0x80000000u;
+    if (nx) s.ox = v2f{next_up(o.x), next_down(o.x)}, s.inv.x = inf;
+    if (ny) s.oy = v2f{next_up(o.y), next_down(o.y)}, s.inv.y = inf;
+    if (nz) s.oz = v2f{next_up(o.z), next_down(o.z)}, s.inv.z = inf;
+    return s;
+}
+
+// Aabb::hit as written (compare-and-assign, no preparation of the ray): for a single test of a box.
+__device__ __forceinline__ bool box_hit_once(float4 a, float4 b, V3 o, V3 d, float lo, float hi) {
+    const V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     v2f tx = (v2f{a.x, a.y} - v2f{o.x, o.x}) * v2f{inv.x, inv.x};
     v2f ty = (v2f{a.z, a.w} - v2f{o.y, o.y}) * v2f{inv.y, inv.y};
     v2f tz = (v2f{b.x, b.y} - v2f{o.z, o.z}) * v2f{inv.z, inv.z};
@@ -106,11 +165,23 @@ __device__ __forceinline__ bool box_hit(float4 a, float4 b, V3 o, V3 inv, float 
     lo = max_raw(lo, s ? tx.x : tx.y);
     hi = min_raw(hi, s ? tx.y : tx.x);
     s = ty.x < ty.y;
-    lo = fmaxf(lo, s ? ty.x : ty.y);
-    hi = fminf(hi, s ? ty.y : ty.x);
+    lo = max_raw(lo, s ? ty.x : ty.y);
+    hi = min_raw(hi, s ? ty.y : ty.x);
     s = tz.x < tz.y;
-    lo = fmaxf(lo, s ? tz.x : tz.y);
-    hi = fminf(hi, s ? tz.y : tz.x);
+    lo = max_raw(lo, s ? tz.x : tz.y);
+    hi = min_raw(hi, s ? tz.y : tz.x);
+    return !(hi <= lo);
+}
+
+// Aabb::hit (see Slabs).  `lo` and `hi` are never NaN.
+__device__ __forceinline__ bool box_hit(float4 a, float4 b, const Slabs &r, float lo, float hi) {
+    v2f tx = (v2f{a.x, a.y} - r.ox) * v2f{r.inv.x, r.inv.x};
+    v2f ty = (v2f{a.z, a.w} - r.oy) * v2f{r.inv.y, r.inv.y};
+    v2f tz = (v2f{b.x, b.y} - r.oz) * v2f{r.inv.z, r.inv.z};
+    lo = max3_raw(lo, min_raw(tx.x, tx.y), min_raw(ty.x, ty.y));
+    hi = min3_raw(hi, max_raw(tx.x, tx.y), max_raw(ty.x, ty.y));
+    lo = max_raw(lo, min_raw(tz.x, tz.y));
+    hi = min_raw(hi, max_raw(tz.x, tz.y));
     return !(hi <= lo);
 }
 
@@ -181,7 +252,7 @@ template <bool COUNT, bool LDS>
 __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ prims,
                                             uint32_t n_nodes, V3 o, V3 d, float tmin, float tmax,
                                             uint32_t &n_nodes_visited, uint32_t &n_tri, uint32_t &n_sph) {
-    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    const Slabs slabs = make_slabs(o, d);
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
     // On the LDS copy the walk runs on byte offsets (32 per node; the copy's skip links are stored that way),
     // which is the address the LDS read wants.
@@ -194,7 +265,7 @@ __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, co
         float4 nlo = node[0];
         float4 nhi = node[1];
         if (COUNT) ++n_nodes_visited;
-        bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+        bool hit = box_hit(nlo, nhi, slabs, tmin, best.t);
         uint32_t leaf = f2u(nhi.w);
         if (hit && leaf != kInterior) {
             uint32_t slot = leaf & ~kSphereBit;
@@ -253,23 +324,15 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
 // not held plus a held (RL, RR) pair: two entries for one level), so at most 2 * depth entries exist at a time; the spill
 // area has room for 2 * depth + 2.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void slab_pair(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, V3 o, V3 inv,
+__device__ __forceinline__ void slab_pair(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, const Slabs &r,
                                           float tmin, float &E, float &X) {
-    v2f tx = (v2f{xlo, xhi} - v2f{o.x, o.x}) * v2f{inv.x, inv.x};
-    v2f ty = (v2f{ylo, yhi} - v2f{o.y, o.y}) * v2f{inv.y, inv.y};
-    v2f tz = (v2f{zlo, zhi} - v2f{o.z, o.z}) * v2f{inv.z, inv.z};
-    bool s = tx.x < tx.y;
-    float lo = max_raw(tmin, s ? tx.x : tx.y);
-    float hi = s ? tx.y : tx.x;
-    hi = (hi != hi) ? __builtin_inff() : hi; // a NaN exit distance leaves the interval as it is
-    s = ty.x < ty.y;
-    lo = max_raw(lo, s ? ty.x : ty.y);
-    hi = min_raw(hi, s ? ty.y : ty.x);
-    s = tz.x < tz.y;
-    lo = max_raw(lo, s ? tz.x : tz.y);
-    hi = min_raw(hi, s ? tz.y : tz.x);
-    E = lo;
-    X = hi;
+    v2f tx = (v2f{xlo, xhi} - r.ox) * v2f{r.inv.x, r.inv.x};
+    v2f ty = (v2f{ylo, yhi} - r.oy) * v2f{r.inv.y, r.inv.y};
+    v2f tz = (v2f{zlo, zhi} - r.oz) * v2f{r.inv.z, r.inv.z};
+    // min / max drop a NaN operand, as compare-and-assign leaves a bound alone (see Slabs); an exit that is NaN on all
+    // three axes stays NaN and is dropped by the caller's min(closest, X)
+    E = max_raw(max3_raw(tmin, min_raw(tx.x, tx.y), min_raw(ty.x, ty.y)), min_raw(tz.x, tz.y));
+    X = min3_raw(max_raw(tx.x, tx.y), max_raw(ty.x, ty.y), max_raw(tz.x, tz.y));
 }
 
 template <int K, int THREADS>
@@ -302,7 +365,8 @@ struct LaneStack {
 template <int K, int THREADS>
 struct StackWalk {
     LaneStack<K, THREADS> stack;
-    V3 o, d, inv;
+    V3 o, d;
+    Slabs slabs;
     float tmin;
     Closest best;
     uint32_t cur;
@@ -316,11 +380,11 @@ struct StackWalk {
     __device__ __forceinline__ void begin(float4 root_lo, float4 root_hi, uint32_t root_ref, V3 origin, V3 dir, float t_min, float t_max) {
         o = origin;
         d = dir;
-        inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+        slabs = make_slabs(o, d);
         best = Closest{t_max, kMissSlot, 0.0f, 0.0f};
         tmin = in_vgpr(t_min);
         float E, X;
-        slab_pair(root_lo.x, root_lo.y, root_lo.z, root_lo.w, root_hi.x, root_hi.y, o, inv, tmin, E, X);
+        slab_pair(root_lo.x, root_lo.y, root_lo.z, root_lo.w, root_hi.x, root_hi.y, slabs, tmin, E, X);
         cur = !(min_raw(best.t, X) <= E) ? root_ref : kRefNone;
     }
     // One pair of children of a node with planes `parent` (xlo, xhi, ylo, yhi, zlo, zhi): plane k of the left
@@ -336,8 +400,8 @@ struct StackWalk {
             left[k] = inherit ? parent[k] : fresh[k];
         }
         float xl, xr;
-        slab_pair(left[0], left[1], left[2], left[3], left[4], left[5], o, inv, tmin, el, xl);
-        slab_pair(right[0], right[1], right[2], right[3], right[4], right[5], o, inv, tmin, er, xr);
+        slab_pair(left[0], left[1], left[2], left[3], left[4], left[5], slabs, tmin, el, xl);
+        slab_pair(right[0], right[1], right[2], right[3], right[4], right[5], slabs, tmin, er, xr);
         hit_l = !(min_raw(best.t, xl) <= el);
         hit_r = !(min_raw(best.t, xr) <= er);
     }
@@ -384,8 +448,8 @@ struct StackWalk {
         const float4 a = p[0], b = p[1], c = p[2], q = p[3], n1 = p[4], nz = p[5], n2 = p[6], refs = p[7];
         const uint32_t meta = f2u(q.z);
         float el, xl, er, xr;
-        slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, el, xl);
-        slab_pair(c.x, c.y, c.z, c.w, b.z, b.w, o, inv, tmin, er, xr);
+        slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, slabs, tmin, el, xl);
+        slab_pair(c.x, c.y, c.z, c.w, b.z, b.w, slabs, tmin, er, xr);
         const bool hit_l = !(min_raw(best.t, xl) <= el);
         const bool hit_r = !(min_raw(best.t, xr) <= er);
         uint32_t r0 = kRefNone, r1 = kRefNone, r2 = kRefNone, r3 = kRefNone; // in visiting order
@@ -466,7 +530,8 @@ __device__ __forceinline__ void load_walk_node(const float4 *__restrict__ nodes,
 // `resume` is where to go on), or kRefNone when the walk is over.  Nodes below `top_bytes` are read from the block's
 // LDS copy of the treetop, the others through the caches.
 struct TopWalk {
-    V3 o, d, inv;
+    V3 o, d;
+    Slabs slabs;
     float tmin;
     Closest best;
     uint32_t cur, resume;
@@ -475,7 +540,7 @@ struct TopWalk {
     __device__ __forceinline__ void begin(float4, float4, uint32_t, V3 origin, V3 dir, float t_min, float t_max) {
         o = origin;
         d = dir;
-        inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+        slabs = make_slabs(o, d);
         best = Closest{t_max, kMissSlot, 0.0f, 0.0f};
         tmin = in_vgpr(t_min);
         cur = 0u; // the root's own box is the first record's
@@ -493,7 +558,7 @@ struct TopWalk {
     __device__ __forceinline__ void step_node(const float4 *__restrict__ nodes, uint32_t lds_top, uint32_t top_bytes) {
         float4 nlo, nhi;
         load_walk_node(nodes, lds_top, top_bytes, cur, nlo, nhi);
-        const bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+        const bool hit = box_hit(nlo, nhi, slabs, tmin, best.t);
         const uint32_t on_hit = f2u(nhi.w), on_miss = f2u(nhi.z);
         if (hit && (on_hit & kRefLeaf)) resume = on_miss;
         cur = hit ? on_hit : on_miss;
@@ -504,14 +569,14 @@ struct TopWalk {
 // primitive at once.
 __device__ __forceinline__ Closest traverse_walk(const float4 *__restrict__ nodes, uint32_t lds_top, uint32_t top_bytes,
                                                  const float4 *__restrict__ prims, V3 o, V3 d, float tmin, float tmax) {
-    const V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    const Slabs slabs = make_slabs(o, d);
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
     tmin = in_vgpr(tmin);
     uint32_t cur = 0u;
     while (cur != kRefNone) {
         float4 nlo, nhi;
         load_walk_node(nodes, lds_top, top_bytes, cur, nlo, nhi);
-        const bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+        const bool hit = box_hit(nlo, nhi, slabs, tmin, best.t);
         const uint32_t on_hit = f2u(nhi.w), on_miss = f2u(nhi.z);
         if (hit && (on_hit & kRefLeaf)) {
             const uint32_t slot = on_hit & kRefIndex;
@@ -942,7 +1007,8 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
 
     bool have = false, exhausted = false;
     uint32_t slot = 0, idx = 0;
-    V3 o{}, d{}, inv{};
+    V3 o{}, d{};
+    Slabs slabs{};
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
     for (;;) {
         const unsigned long long idle_mask = ballot(!have);
@@ -965,7 +1031,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
                     if (ok) {
                         o = xyz(ray_o[slot]);
                         d = xyz(ray_d[slot]);
-                        inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+                        slabs = make_slabs(o, d);
                         best = Closest{tmax, kMissSlot, 0.0f, 0.0f};
                         idx = 0;
                         have = true;
@@ -983,7 +1049,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, const float4 *__
             float4 nhi = nodes[2 * idx + 1];
             if (LDS_SCENE) nhi.z = u2f(f2u(nhi.z) >> 5); // the LDS copy stores skip links as byte offsets
             if (COUNT) ++c_nodes;
-            bool hit = box_hit(nlo, nhi, o, inv, tmin, best.t);
+            bool hit = box_hit(nlo, nhi, slabs, tmin, best.t);
             uint32_t leaf = f2u(nhi.w);
             if (hit && leaf != kInterior) {
                 uint32_t ps = leaf & ~kSphereBit;
@@ -1085,9 +1151,7 @@ __device__ __forceinline__ int shade_segment(const SceneDev &sc, float4 root_lo,
             // src/renderer.rs:39-41: `while beta != 0` then `depth >= max_depth`
             alive = !(beta.x == 0.0f && beta.y == 0.0f && beta.z == 0.0f) && depth < P.max_depth;
             if (alive) {
-                V3 nd = sr.direction;
-                V3 ninv = V3{1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z};
-                if (!box_hit(root_lo, root_hi, s.point, ninv, P.z_near, P.z_far)) {
+                if (!box_hit_once(root_lo, root_hi, s.point, sr.direction, P.z_near, P.z_far)) {
                     alive = false;
                     early_miss = true;
                     l = ld3(P.background);

@@ -243,7 +243,11 @@ def random_scene(seed):
 #              pixels finite in all three images
 #   rmse       per channel RMSE(g, a) and RMSE(g, b) over the same pixels must be <= 3 sigma_mc (two independent
 #              unbiased renders differ by sqrt(2) sigma_mc), and their ratio to RMSE(a, b) must lie in
-#              [0.75, 1.33] (same per-pixel variance)
+#              [0.75, 1.33] (same per-pixel variance).  Before the RMSEs are taken, values are clamped to the 99.9th
+#              percentile of the two reference images' finite values: the per-sample square root leaves a heavy tail
+#              (a handful of pixels that caught the light through a rare path), and one such pixel present in one
+#              image and absent from the other two would otherwise decide the whole-image RMSE (the oracle's
+#              per-thread generator hands work to threads dynamically, so a and b differ from run to run)
 #   luminance  mean Rec. 709 luminance over each image's finite pixels: |lum(g) - lum(a or b)| <= the larger of
 #              1 % and four standard errors of that difference (from the per-pixel variance)
 #   inf        fraction of pixels holding an infinity: within 20 % (relative) of a's and b's, plus 2e-4 absolute
@@ -253,7 +257,8 @@ def image_tolerance_report(g, a, b):
     fin = (np.isfinite(g) & np.isfinite(a) & np.isfinite(b)).all(axis=2)
     rep = {"finite_pixels": int(fin.sum()), "channels": []}
     for c in range(3):
-        rm = lambda x, y: float(np.sqrt(np.mean((x[..., c][fin] - y[..., c][fin]) ** 2)))
+        cap = float(np.percentile(np.concatenate([a[..., c][fin], b[..., c][fin]]), 99.9))
+        rm = lambda x, y: float(np.sqrt(np.mean((np.minimum(x[..., c][fin], cap) - np.minimum(y[..., c][fin], cap)) ** 2)))
         ab, ga, gb = rm(a, b), rm(g, a), rm(g, b)
         rep["channels"].append({"sigma_mc": ab / np.sqrt(2.0), "rmse_ab": ab, "rmse_ga": ga, "rmse_gb": gb})
     w = np.array([0.2126, 0.7152, 0.0722])

@@ -40,6 +40,63 @@ def assert_images_equal(gpu, cpu, min_agree=1.0):
     assert same.mean() >= min_agree, f"{np.count_nonzero(~same)} of {same.size} values differ"
 
 
+@pytest.mark.parametrize("name", ["cornell", "teapot", "rtiow"])
+def test_signed_zero_directions_with_origins_on_box_planes(cornell, teapot, name):
+    """Aabb::hit (src/aabb.rs:95-127) with a direction component of exactly +0 or -0 and the origin exactly on, one
+    binary32 below and one above a plane of a node's box: 1 / +0 = +inf, 1 / -0 = -inf and (plane - origin) * inf is a
+    NaN on the plane itself, which compare-and-assign treats differently for the two signs (with -0 a box is passed by an
+    origin ON its plane, with +0 it is not).  The slab test orders distances with min / max and handles -0 by a
+    per-ray substitution; here every box decision is checked through the instrumented kernel's visit counts, which
+    must equal the oracle's, next to the hits themselves."""
+    desc = {"cornell": cornell, "teapot": teapot}.get(name) or rtiow_final_scene()[0]
+    ctx = Context(0, flags=F.RT_CTX_COUNTERS)
+    g, o = both(ctx, desc)
+    boxes, _, _ = o.export_bvh()
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 6)
+    rng = np.random.default_rng(77)
+    pick = rng.permutation(len(boxes))[:600]
+    root_lo, root_hi = boxes[0, :3], boxes[0, 3:]
+    rays = []
+    for node in pick:
+        for axis in range(3):
+            for plane in (boxes[node, axis], boxes[node, 3 + axis]):
+                for step in (-1, 0, 1):
+                    for zero in (np.float32(0.0), np.float32(-0.0)):
+                        org = (root_lo + (root_hi - root_lo) * rng.random(3, dtype=np.float32)).astype(np.float32)
+                        at = np.float32(plane)
+                        if step:
+                            at = np.nextafter(at, np.float32(np.inf if step > 0 else -np.inf), dtype=np.float32)
+                        org[axis] = at
+                        d = rng.normal(size=3).astype(np.float32)
+                        d[axis] = zero
+                        if rng.random() < 0.25:  # a second zero, of either sign
+                            d[(axis + 1) % 3] = np.float32(-0.0) if rng.random() < 0.5 else np.float32(0.0)
+                        # aim at the node's box so that the ray meets it and its neighbours
+                        centre = (boxes[node, :3] + boxes[node, 3:]) * np.float32(0.5)
+                        other = (axis + 2) % 3
+                        d[other] = np.float32(centre[other] - org[other]) or np.float32(1.0)
+                        rays.append((org, d))
+    arr = np.zeros(len(rays), dtype=F.RAY_DTYPE)
+    arr["origin"] = np.array([r[0] for r in rays], np.float32)
+    arr["direction"] = np.array([r[1] for r in rays], np.float32)
+    assert (np.signbit(arr["direction"]) & (arr["direction"] == 0)).sum() > len(arr) // 3  # the -0 components made it through
+    for t_min, t_max in ((1e-4, np.inf), (-1.0, 50.0)):
+        got, gst = g.trace_closest(arr, t_min, t_max)
+        want, ost = o.trace_closest(arr, t_min, t_max)
+        assert_hits_equal(got, want)
+        assert (gst.node_visits, gst.triangle_tests, gst.sphere_tests) == (ost.node_visits, ost.triangle_tests, ost.sphere_tests)
+    # the same rays through the uninstrumented kernels (LDS tables, one lane per ray over the walk table and the chain records)
+    plain = Context(0)
+    g2 = Scene(plain, desc)
+    got, _ = g2.trace_closest(arr, 1e-4, np.inf)
+    want, _ = o.trace_closest(arr, 1e-4, np.inf)
+    assert_hits_equal(got, want)
+    g2.close()
+    plain.close()
+    g.close()
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # closest hit
 # ---------------------------------------------------------------------------------------------------------
