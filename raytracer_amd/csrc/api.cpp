@@ -102,6 +102,9 @@ struct rt_context {
     // launch shape of the lanes kernel over the walk table, 0 = default (RT_WALK_THREADS, RT_WALK_BLOCKS_PER_CU, RT_WALK_TOP_KB)
     uint32_t walk_threads = 0, walk_blocks_per_cu = 0;
     int64_t walk_top_bytes = -1;
+    // the same for the chain walk (RT_CHAIN_THREADS, RT_CHAIN_TOP_RECORDS)
+    uint32_t chain_threads = 0;
+    int64_t chain_top_records = -1;
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
     // wavefront workspace
@@ -138,6 +141,7 @@ struct rt_scene {
     // (ensure_chain / ensure_walk): dev.chain / dev.walk_nodes stay nullptr until then.
     std::mutex derived_mutex;
     uint32_t walk_region_bytes = 0; // bytes at the start of the walk table any prefix of which is a treetop
+    uint32_t chain_top_made_for = 0; // record count dev.chain_top was made for (ensure_chain_top)
     std::vector<uint32_t> prim_of_slot;
     rt_scene_info info{};
     bool need_uv = false;
@@ -271,6 +275,65 @@ int ensure_chain(rt_context *c, const rt_scene *cs) {
     return RT_OK;
 }
 
+// Copies of the `want` chain records nearest the root for the lanes kernel to keep in LDS: breadth first over the records a
+// walk visits (a record that holds a pair of grandchildren is followed by the grandchildren's records, else by the
+// child's), child references that point into the copy tagged with kRefTop.  A copy serves exactly the count it was made
+// for (its tagged references name slots up to that count), so it is remade when a launch asks for another count.
+int ensure_chain_top(rt_context *c, const rt_scene *cs, uint32_t want) {
+    rt_scene *s = const_cast<rt_scene *>(cs);
+    std::lock_guard<std::mutex> lock(s->derived_mutex);
+    want = std::min(want, s->dev.n_prims > 1u ? s->dev.n_prims - 1u : 0u);
+    if (s->chain_top_made_for == want) return RT_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream)); // launches that read the old copy have finished
+    if (s->dev.chain_top) {
+        for (int i = 0; i < s->n_blocks; ++i)
+            if (s->blocks[i] == s->dev.chain_top) s->blocks[i] = nullptr;
+        (void)hipFree(const_cast<rt::ChainNode *>(s->dev.chain_top));
+        s->dev.chain_top = nullptr;
+        s->dev.n_chain_top = 0;
+    }
+    s->chain_top_made_for = want;
+    if (want == 0) return RT_OK;
+    std::vector<uint32_t> order{0u};
+    std::vector<rt::ChainNode> recs;
+    for (size_t i = 0; i < order.size(); ++i) {
+        rt::ChainNode r;
+        HIP_TRY(hipMemcpy(&r, s->dev.chain + order[i], sizeof r, hipMemcpyDeviceToHost));
+        recs.push_back(r);
+        const uint32_t next[4] = {(r.meta & (1u << 16)) ? r.ll : r.left, (r.meta & (1u << 16)) ? r.lr : rt::kRefNone,
+                                  (r.meta & (1u << 17)) ? r.rl : r.right, (r.meta & (1u << 17)) ? r.rr : rt::kRefNone};
+        for (uint32_t ref : next)
+            if (!(ref & rt::kRefLeaf) && order.size() < want) order.push_back(ref);
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> slot_of(order.size());
+    for (size_t k = 0; k < order.size(); ++k) slot_of[k] = {order[k], (uint32_t)k};
+    std::sort(slot_of.begin(), slot_of.end());
+    auto patch = [&](uint32_t &ref) {
+        if (ref & rt::kRefLeaf) return;
+        auto it = std::lower_bound(slot_of.begin(), slot_of.end(), std::make_pair(ref, 0u));
+        if (it != slot_of.end() && it->first == ref) ref = rt::kRefTop | it->second;
+    };
+    for (rt::ChainNode &r : recs) {
+        patch(r.left), patch(r.right);
+        if (r.meta & (1u << 16)) patch(r.ll), patch(r.lr);
+        if (r.meta & (1u << 17)) patch(r.rl), patch(r.rr);
+    }
+    void *t = nullptr;
+    HIP_TRY(hipMalloc(&t, recs.size() * sizeof(rt::ChainNode)));
+    if (hipMemcpy(t, recs.data(), recs.size() * sizeof(rt::ChainNode), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(t);
+        return set_error(RT_ERR_DEVICE, "uploading the top chain records failed");
+    }
+    int at = -1;
+    for (int i = 0; i < s->n_blocks; ++i)
+        if (!s->blocks[i]) at = i;
+    if (at < 0) at = s->n_blocks++;
+    s->blocks[at] = t;
+    s->dev.chain_top = static_cast<const rt::ChainNode *>(t);
+    s->dev.n_chain_top = (uint32_t)recs.size();
+    return RT_OK;
+}
+
 // The walk table (WalkNode) of a scene, built on the host from a copy of its node table the first time a traversal asks.
 int ensure_walk(rt_context *c, const rt_scene *cs) {
     rt_scene *s = const_cast<rt_scene *>(cs);
@@ -346,6 +409,14 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
     if (const char *e = std::getenv("RT_WALK_BLOCKS_PER_CU")) {
         long v = std::strtol(e, nullptr, 10);
         if (v >= 1 && v <= 8) c->walk_blocks_per_cu = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("RT_CHAIN_THREADS")) {
+        long v = std::strtol(e, nullptr, 10);
+        if (v == 256 || v == 512 || v == 1024) c->chain_threads = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("RT_CHAIN_TOP_RECORDS")) {
+        long v = std::strtol(e, nullptr, 10);
+        if (v >= 0 && v <= 1200) c->chain_top_records = v;
     }
     if (const char *e = std::getenv("RT_WALK_TOP_KB")) {
         long v = std::strtol(e, nullptr, 10);
@@ -827,14 +898,33 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // eight waves per SIMD (64 registers, spills) 1024 x 2 4.50 / 7.05.
     const uint32_t walk_threads = c->walk_threads ? c->walk_threads : 768u;
     const uint32_t walk_blocks_per_cu = c->walk_blocks_per_cu ? c->walk_blocks_per_cu : std::max(1u, blocks_per_cu * 256u / walk_threads);
-    uint32_t walk_grid = grid;
-    rt::SceneDev dev = s->dev;
+    uint32_t walk_grid = grid, lanes_threads = 256u;
+    uint32_t top_bytes = 0;
     if (lanes_walk) {
         walk_grid = std::min(c->cus * walk_blocks_per_cu, chunks);
         const uint32_t segs = std::min(32u, std::max(1u, (grid + walk_grid - 1) / walk_grid));
         grid = walk_grid * segs;
-        dev.top_bytes = top_bytes_for(s, c, walk_blocks_per_cu);
+        top_bytes = top_bytes_for(s, c, walk_blocks_per_cu);
+        lanes_threads = walk_threads;
+    } else if (lanes_chain) {
+        // The chain walk keeps its stacks in LDS (K entries x 8 bytes per lane); what a CU's LDS has left holds copies of
+        // the records nearest the root, which every walk reads, and one block of 1024 threads per CU shares one copy
+        // instead of four.  10 M / 1 M soup, Grays/s: no copy 0.729 / 1.300; 256 x 4 blocks, 56 records 0.800 / 1.379; 512 x 2,
+        // 120 records 0.823 / 1.428; 1024 x 1, 248 records 0.863 / 1.493; with 8 instead of 16 stack entries in LDS and 184 /
+        // 376 / 760 records 0.788 / 1.405, 0.804 / 1.461, 0.842 / 1.561.
+        lanes_threads = c->chain_threads ? c->chain_threads : 1024u;
+        const uint32_t per_cu = std::max(1u, blocks_per_cu * 256u / lanes_threads);
+        walk_grid = std::min(c->cus * per_cu, chunks);
+        const uint32_t segs = std::min(32u, std::max(1u, (grid + walk_grid - 1) / walk_grid));
+        grid = walk_grid * segs;
+        const uint32_t stack_bytes = (uint32_t)rt::kStackEntriesInLds * lanes_threads * 8u;
+        const uint32_t budget = (160u * 1024u) / per_cu;
+        const uint32_t fit = budget > stack_bytes + 1024u ? (budget - stack_bytes - 1024u) / (uint32_t)sizeof(rt::ChainNode) : 0u;
+        const uint32_t want = c->chain_top_records >= 0 ? std::min<uint32_t>((uint32_t)c->chain_top_records, fit) : fit;
+        if (int rc = ensure_chain_top(c, s, want)) return rc;
     }
+    rt::SceneDev dev = s->dev;
+    dev.top_bytes = top_bytes;
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
     if (int rc = ensure_render(c, lanes ? 0 : slots, lanes ? 0 : (size_t)grid * cap, st->max_depth, grid)) return rc;
     if (int rc = c->radiance.ensure(slots)) return rc;
@@ -845,7 +935,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
         if (int rc = c->queue[0].ensure((size_t)grid * cap)) return rc;
     }
     const uint32_t block_threads = big_blocks ? 1024u : 256u;
-    rt::StackSpill spill{nullptr, grid * block_threads};
+    rt::StackSpill spill{nullptr, std::max(grid * block_threads, walk_grid * lanes_threads)};
     if (stack) { // at most two pending entries per interior level (see StackWalk)
         if (int rc = c->stack_spill.ensure((size_t)(2u * s->dev.depth + 2u) * spill.stride)) return rc;
         spill.spill = c->stack_spill.ptr;
@@ -903,7 +993,7 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
             if (int rc = timed_begin(c, K_BOUNCE)) return rc;
             if (lanes)
                 rt::launch_paths_lanes(c->stream, grid, dev, P, ps, n, cap, c->queue[0].ptr, c->counts.ptr, c->early.ptr, s->need_uv,
-                                       s->has_mix, lanes_waves, spill, lanes_lockstep_first, lanes_chain, walk_threads, walk_grid);
+                                       s->has_mix, lanes_waves, spill, lanes_lockstep_first, lanes_chain, lanes_threads, walk_grid);
             else
                 rt::launch_paths(c->stream, grid, s->dev, P, ps, n, cap, c->queue[0].ptr, c->queue[1].ptr, c->counts.ptr,
                                  c->early.ptr, s->need_uv, s->has_mix, lds_bytes, big_blocks, eight_waves);

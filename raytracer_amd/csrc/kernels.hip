@@ -324,6 +324,43 @@ __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, fl
 // not held plus a held (RL, RR) pair: two entries for one level), so at most 2 * depth entries exist at a time; the spill
 // area has room for 2 * depth + 2.
 // ------------------------------------------------------------------------------------------------------
+// The 128 bytes of a chain record for every active lane: from the block's LDS copy of the top records when `in_top`
+// (at LDS address `lds_at`), else from device memory at `p`; both kinds of loads issued under their own execution
+// mask and awaited together (see load_walk_node).
+__device__ __forceinline__ void load_chain_record(const float4 *__restrict__ p, uint32_t lds_at, bool in_top, float4 out[8]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f r0, r1, r2, r3, r4, r5, r6, r7;
+    unsigned long long saved;
+    const unsigned long long top = ballot(in_top);
+    asm volatile("s_and_saveexec_b64 %[saved], %[top]\n\t"
+                 "ds_read_b128 %[r0], %[la]\n\t"
+                 "ds_read_b128 %[r1], %[la] offset:16\n\t"
+                 "ds_read_b128 %[r2], %[la] offset:32\n\t"
+                 "ds_read_b128 %[r3], %[la] offset:48\n\t"
+                 "ds_read_b128 %[r4], %[la] offset:64\n\t"
+                 "ds_read_b128 %[r5], %[la] offset:80\n\t"
+                 "ds_read_b128 %[r6], %[la] offset:96\n\t"
+                 "ds_read_b128 %[r7], %[la] offset:112\n\t"
+                 "s_andn2_b64 exec, %[saved], %[top]\n\t"
+                 "global_load_dwordx4 %[r0], %[ga], off\n\t"
+                 "global_load_dwordx4 %[r1], %[ga], off offset:16\n\t"
+                 "global_load_dwordx4 %[r2], %[ga], off offset:32\n\t"
+                 "global_load_dwordx4 %[r3], %[ga], off offset:48\n\t"
+                 "global_load_dwordx4 %[r4], %[ga], off offset:64\n\t"
+                 "global_load_dwordx4 %[r5], %[ga], off offset:80\n\t"
+                 "global_load_dwordx4 %[r6], %[ga], off offset:96\n\t"
+                 "global_load_dwordx4 %[r7], %[ga], off offset:112\n\t"
+                 "s_mov_b64 exec, %[saved]\n\t"
+                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5), [r6] "=&v"(r6),
+                   [r7] "=&v"(r7), [saved] "=&s"(saved)
+                 : [top] "s"(top), [la] "v"(lds_at), [ga] "v"(p)
+                 : "memory");
+    const v4f r[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
+}
+
 __device__ __forceinline__ void slab_pair(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, const Slabs &r,
                                           float tmin, float &E, float &X) {
     v2f tx = (v2f{xlo, xhi} - r.ox) * v2f{r.inv.x, r.inv.x};
@@ -443,9 +480,20 @@ struct StackWalk {
     // child at that later moment, and since R passed now (so its exit lies beyond its entry) and the child's own
     // exit-against-entry test is done now, what is left for later is "closest > R's entry and closest > the child's
     // entry": the entry pushed with the child is the larger of the two.
-    __device__ __forceinline__ void step_node(const float4 *__restrict__ chain) {
-        const float4 *__restrict__ p = chain + 8 * (size_t)cur;
-        const float4 a = p[0], b = p[1], c = p[2], q = p[3], n1 = p[4], nz = p[5], n2 = p[6], refs = p[7];
+    // `lds_top`: LDS address of the block's copy of the top records (read when cur carries kRefTop); kRefNone when the
+    // launch stages none.
+    __device__ __forceinline__ void step_node(const float4 *__restrict__ chain, uint32_t lds_top = kRefNone) {
+        float4 rec[8];
+        if (lds_top == kRefNone) {
+            const float4 *__restrict__ p = chain + 8 * (size_t)cur;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rec[i] = p[i];
+        } else {
+            const bool in_top = (cur & kRefTop) != 0u;
+            const uint32_t at = cur & ~kRefTop;
+            load_chain_record(chain + 8 * (size_t)at, lds_top + at * 128u, in_top, rec);
+        }
+        const float4 a = rec[0], b = rec[1], c = rec[2], q = rec[3], n1 = rec[4], nz = rec[5], n2 = rec[6], refs = rec[7];
         const uint32_t meta = f2u(q.z);
         float el, xl, er, xr;
         slab_pair(a.x, a.y, a.z, a.w, b.x, b.y, slabs, tmin, el, xl);
@@ -1451,7 +1499,6 @@ template <bool NEED_UV, bool HAS_MIX, int WAVES, int K, bool FROM_CAMERA, bool C
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX ? 4 : WAVES))) void k_paths_lanes(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, const uint32_t *__restrict__ queue,
     const uint32_t *__restrict__ pool, uint32_t *__restrict__ ray_counts, StackSpill spill, uint32_t segs) {
-    static_assert(!CHAIN || THREADS == kBlock, "the stack area of the chain walk is laid out for 256-thread blocks");
     extern __shared__ float4 s_scene[];
     __shared__ uint32_t s_next, s_rays;
     __shared__ uint32_t s_first[kMaxSegs + 1]; // !FROM_CAMERA: item index of the first entry of each of the block's segments
@@ -1470,9 +1517,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
             s_first[segs] = acc;
         }
     }
+    uint32_t chain_lds = kRefNone, root_ref = sc.root_ref;
     if constexpr (!CHAIN) { // the treetop of the walk table
         const uint32_t n4 = sc.top_bytes / 16u;
         for (uint32_t i = threadIdx.x; i < n4; i += THREADS) s_scene[i] = chain[i];
+    } else if (sc.n_chain_top != 0u) { // the top chain records, behind the stack area
+        float4 *dst = s_scene + (size_t)K * THREADS / 2;
+        const float4 *__restrict__ src = reinterpret_cast<const float4 *>(sc.chain_top);
+        for (uint32_t i = threadIdx.x; i < sc.n_chain_top * 8u; i += THREADS) dst[i] = src[i];
+        chain_lds = lds_address(dst);
+        if ((root_ref & kRefLeaf) == 0u) root_ref = kRefTop; // slot 0 is the root's record
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1484,7 +1538,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
         my_items = s_first[segs];
     }
 
-    typename std::conditional<CHAIN, StackWalk<K, kBlock>, TopWalk>::type walk;
+    typename std::conditional<CHAIN, StackWalk<K, THREADS>, TopWalk>::type walk;
     walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
     Segment g{};
     uint32_t slot = 0, s_local = 0, pixel = 0, n_rays = 0;
@@ -1513,7 +1567,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
                 g.d = walk.d;
                 const int outcome = shade_segment<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, g, s_local, pixel, walk.best, l);
                 if (outcome == kPathAlive) {
-                    walk.begin(root_lo, root_hi, sc.root_ref, g.o, g.d, P.z_near, P.z_far);
+                    walk.begin(root_lo, root_hi, root_ref, g.o, g.d, P.z_near, P.z_far);
                     ++n_rays;
                 } else {
                     st.radiance[slot] = mk4(l, 0.0f);
@@ -1544,7 +1598,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
                             g.depth = f2u(d4.w) & 0xFFFFu;
                             s_local = f2u(d4.w) >> 16;
                             pixel = slot - s_local * P.npix;
-                            walk.begin(root_lo, root_hi, sc.root_ref, g.o, g.d, P.z_near, P.z_far);
+                            walk.begin(root_lo, root_hi, root_ref, g.o, g.d, P.z_near, P.z_far);
                             have = true;
                         }
                     } else {
@@ -1555,7 +1609,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
                             g.beta = V3{1.0f, 1.0f, 1.0f};
                             g.flags = 0u;
                             g.depth = 0u;
-                            walk.begin(root_lo, root_hi, sc.root_ref, g.o, g.d, P.z_near, P.z_far);
+                            walk.begin(root_lo, root_hi, root_ref, g.o, g.d, P.z_near, P.z_far);
                             have = true;
                         }
                     }
@@ -1592,7 +1646,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
                 if (leaf_lane) walk.step_leaf(prims);
             } else {
                 if constexpr (CHAIN) {
-                    if (node_lane) walk.step_node(chain);
+                    if (node_lane) walk.step_node(chain, chain_lds);
                 } else {
                     if (node_lane) walk.step_node(chain, lds_address(s_scene), sc.top_bytes);
                 }
@@ -1914,16 +1968,22 @@ void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const 
                            ray_counts, spill, grid / walk_grid);
         return;
     }
-    const uint32_t stack_bytes = (uint32_t)(K * kBlock * sizeof(uint2));
     if (camera_rays_in_lockstep) { // bounce 0 by the per-bounce kernel: survivors into `queue`, rows 1 of the tables
         const QueueView all{nullptr, nullptr, cap, n_slots};
         auto first = has_mix ? k_bounce<true, false, true, true, K> : need_uv ? k_bounce<true, false, true, false, K> : k_bounce<true, false, false, false, K>;
-        hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), stack_bytes, s, sc, P, st, all, queue, counts + grid, early + grid, spill);
+        hipLaunchKernelGGL(first, dim3(grid), dim3(kBlock), (uint32_t)(K * kBlock * sizeof(uint2)), s, sc, P, st, all, queue, counts + grid,
+                           early + grid, spill);
         if (P.max_depth < 2u) return;
     }
     LanesKernel kernel;
 #define RT_LANES_KERNEL(FROM_CAMERA)                                                                                             \
-    (has_mix      ? k_paths_lanes<true, true, 4, K, FROM_CAMERA>                                                                   \
+    (walk_threads == 1024u ? (has_mix ? k_paths_lanes<true, true, 4, K, FROM_CAMERA, true, 1024>                                   \
+                              : need_uv ? k_paths_lanes<true, false, 4, K, FROM_CAMERA, true, 1024>                                \
+                                        : k_paths_lanes<false, false, 4, K, FROM_CAMERA, true, 1024>)                              \
+     : walk_threads == 512u ? (has_mix ? k_paths_lanes<true, true, 4, K, FROM_CAMERA, true, 512>                                   \
+                               : need_uv ? k_paths_lanes<true, false, 4, K, FROM_CAMERA, true, 512>                                \
+                                         : k_paths_lanes<false, false, 4, K, FROM_CAMERA, true, 512>)                              \
+     : has_mix    ? k_paths_lanes<true, true, 4, K, FROM_CAMERA>                                                                   \
      : waves >= 8 ? (need_uv ? k_paths_lanes<true, false, 8, K, FROM_CAMERA> : k_paths_lanes<false, false, 8, K, FROM_CAMERA>)     \
      : waves >= 6 ? (need_uv ? k_paths_lanes<true, false, 6, K, FROM_CAMERA> : k_paths_lanes<false, false, 6, K, FROM_CAMERA>)     \
      : waves >= 5 ? (need_uv ? k_paths_lanes<true, false, 5, K, FROM_CAMERA> : k_paths_lanes<false, false, 5, K, FROM_CAMERA>)     \
@@ -1933,9 +1993,14 @@ void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const 
     else
         kernel = RT_LANES_KERNEL(true);
 #undef RT_LANES_KERNEL
+    const uint32_t threads = (walk_threads == 1024u || walk_threads == 512u) ? walk_threads : kBlock;
+    const uint32_t lds_bytes = (uint32_t)(K * threads * sizeof(uint2)) + sc.n_chain_top * (uint32_t)sizeof(ChainNode);
+    if (lds_bytes > 48u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     // rays beyond those the tables already hold: bounce 0's survivors are row 1, so the lanes' own count is row 2
     uint32_t *ray_counts = counts + (size_t)(camera_rays_in_lockstep ? 2u : 1u) * grid;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), stack_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid, ray_counts, spill, 1u);
+    hipLaunchKernelGGL(kernel, dim3(walk_grid), dim3(threads), lds_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid, ray_counts, spill,
+                       grid / walk_grid);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -63,6 +63,10 @@ constexpr uint32_t kRefLeaf = 0x80000000u;
 constexpr uint32_t kRefSphere = 0x40000000u;
 constexpr uint32_t kRefIndex = 0x3FFFFFFFu;
 constexpr uint32_t kRefNone = 0xFFFFFFFFu;
+// Set in the reference of an interior node whose record is read from the block's LDS copy of the tree's top records
+// (SceneDev::chain_top): the low bits are then the record's slot in that copy.  Only references stored IN that copy carry
+// it (and the root's, set by the kernel); the records in device memory never do.
+constexpr uint32_t kRefTop = 0x20000000u;
 
 // The same tree a third time, for the one-lane-per-path walk over scenes that sit in the L2s: the 32-byte nodes of the
 // pre-order table with BOTH successors explicit, as byte offsets into this table (what an LDS read and a
@@ -147,6 +151,9 @@ struct SceneDev {
     const uint8_t *texels;
     const uint32_t *slot_of_prim; // primitive ID -> slot in `prims` (object-list order for World::hit)
     const ChainNode *chain;       // n_prims - 1 records; nullptr when the table was not built
+    const ChainNode *chain_top;   // copies of the chain records nearest the root, level by level, child references into
+                                  // the copy itself tagged with kRefTop; staged in LDS by the lanes kernel
+    uint32_t n_chain_top;         // records in chain_top (0: none)
     const WalkNode *walk_nodes;   // n_nodes records, treetop first; nullptr when the table was not built
     uint32_t top_bytes;           // bytes of walk_nodes that form the treetop (a multiple of 32)
     uint32_t root_ref;            // child reference of the root (a leaf reference for a one-primitive scene)
