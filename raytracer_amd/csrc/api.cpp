@@ -135,8 +135,7 @@ struct rt_context {
 struct rt_scene {
     int device = 0;
     rt::SceneDev dev{};
-    void *blocks[12] = {};
-    int n_blocks = 0;
+    std::vector<void *> blocks; // device allocations the scene owns
     // The chain records and the walk table are derived from the node table when a traversal first asks for them
     // (ensure_chain / ensure_walk): dev.chain / dev.walk_nodes stay nullptr until then.
     std::mutex derived_mutex;
@@ -234,7 +233,7 @@ template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **ds
     size_t n = v.size() ? v.size() : 1;
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, n * sizeof(T)));
-    s->blocks[s->n_blocks++] = p;
+    s->blocks.push_back(p);
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T *>(p);
     bytes += n * sizeof(T);
@@ -269,7 +268,7 @@ int ensure_chain(rt_context *c, const rt_scene *cs) {
         (void)hipFree(p);
         return set_error(RT_ERR_DEVICE, "building the BVH node records failed");
     }
-    s->blocks[s->n_blocks++] = p;
+    s->blocks.push_back(p);
     s->dev.chain = static_cast<const rt::ChainNode *>(p);
     s->info.device_bytes += bytes;
     return RT_OK;
@@ -284,14 +283,10 @@ int ensure_chain_top(rt_context *c, const rt_scene *cs, uint32_t want) {
     std::lock_guard<std::mutex> lock(s->derived_mutex);
     want = std::min(want, s->dev.n_prims > 1u ? s->dev.n_prims - 1u : 0u);
     if (s->chain_top_made_for == want) return RT_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream)); // launches that read the old copy have finished
-    if (s->dev.chain_top) {
-        for (int i = 0; i < s->n_blocks; ++i)
-            if (s->blocks[i] == s->dev.chain_top) s->blocks[i] = nullptr;
-        (void)hipFree(const_cast<rt::ChainNode *>(s->dev.chain_top));
-        s->dev.chain_top = nullptr;
-        s->dev.n_chain_top = 0;
-    }
+    // An older copy stays allocated until the scene is destroyed (a launch on another stream may still read it); a
+    // launch shape, and with it the count, changes only when a tuning knob does.
+    s->dev.chain_top = nullptr;
+    s->dev.n_chain_top = 0;
     s->chain_top_made_for = want;
     if (want == 0) return RT_OK;
     std::vector<uint32_t> order{0u};
@@ -324,11 +319,7 @@ int ensure_chain_top(rt_context *c, const rt_scene *cs, uint32_t want) {
         (void)hipFree(t);
         return set_error(RT_ERR_DEVICE, "uploading the top chain records failed");
     }
-    int at = -1;
-    for (int i = 0; i < s->n_blocks; ++i)
-        if (!s->blocks[i]) at = i;
-    if (at < 0) at = s->n_blocks++;
-    s->blocks[at] = t;
+    s->blocks.push_back(t);
     s->dev.chain_top = static_cast<const rt::ChainNode *>(t);
     s->dev.n_chain_top = (uint32_t)recs.size();
     return RT_OK;
@@ -354,7 +345,7 @@ int ensure_walk(rt_context *c, const rt_scene *cs) {
             (void)hipFree(p);
             return set_error(RT_ERR_DEVICE, "uploading the walk table failed");
         }
-        s->blocks[s->n_blocks++] = p;
+        s->blocks.push_back(p);
         s->walk_region_bytes = (uint32_t)(region * sizeof(rt::WalkNode));
         s->dev.walk_nodes = static_cast<const rt::WalkNode *>(p);
         s->info.device_bytes += table.size() * sizeof(rt::WalkNode);
@@ -526,7 +517,7 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
             e = "out of device memory for the BVH nodes";
             return RT_ERR_OUT_OF_MEMORY;
         }
-        s->blocks[s->n_blocks++] = p;
+        s->blocks.push_back(p);
         d_nodes = static_cast<rt::Node *>(p);
         return rt::build_bvh_device(c->stream, boxes, n, sphere_begin, sphere_end, d_nodes, order.data(), &depth, e);
     };
@@ -591,8 +582,8 @@ RT_API int rt_scene_create(rt_context *c, const rt_scene_desc *desc, rt_scene **
 RT_API int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     DeviceGuard guard(s->device);
-    for (int i = 0; i < s->n_blocks; ++i)
-        if (s->blocks[i]) (void)hipFree(s->blocks[i]);
+    for (void *p : s->blocks)
+        if (p) (void)hipFree(p);
     delete s;
     return RT_OK;
 }
@@ -725,8 +716,15 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     if (lanes) {
         const bool chain = s->dev.n_prims <= rt::kRefIndex && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (2u << 20)));
         if (int rc = chain ? ensure_chain(c, s) : ensure_walk(c, s)) return rc;
-        const uint32_t lanes_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cus * (chain ? 4u : 6u), (n + 255) / 256);
-        rt::StackSpill spill{nullptr, lanes_grid * 256u};
+        // chain: one 1024-thread block per CU (16 waves: four per SIMD), else six 256-thread blocks
+        const uint32_t lanes_grid = chain ? (uint32_t)std::min<uint64_t>(c->cus, (n + 1023) / 1024)
+                                          : (uint32_t)std::min<uint64_t>((uint64_t)c->cus * 6u, (n + 255) / 256);
+        rt::StackSpill spill{nullptr, lanes_grid * (chain ? 1024u : 256u)};
+        if (chain) {
+            const uint32_t stack_bytes = (uint32_t)rt::kStackEntriesInLds * 1024u * 8u;
+            const uint32_t fit = (160u * 1024u - stack_bytes - 1024u) / (uint32_t)sizeof(rt::ChainNode);
+            if (int rc = ensure_chain_top(c, s, c->chain_top_records >= 0 ? std::min<uint32_t>((uint32_t)c->chain_top_records, fit) : fit)) return rc;
+        }
         rt::SceneDev dev = s->dev;
         if (chain) {
             // at most two pending entries per interior level (see StackWalk)

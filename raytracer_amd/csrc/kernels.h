@@ -15,7 +15,8 @@ void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, 
 
 // `lds_bytes` != 0 stages the node and primitive tables in LDS (see launch_bounce).
 // Closest hits with one lane per ray (k_extend_lanes): the stack traversal over the chain records when `chain`, else
-// the stackless walk; `spill` as for launch_paths_lanes (stride = grid * 256).  hits[i] belongs to ray i.
+// the stackless walk; `spill` as for launch_paths_lanes.  Blocks of 1024 threads when `chain` (stride = grid * 1024), else
+// of 256.  hits[i] belongs to ray i.
 void launch_extend_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d, float4 *hits,
                          uint32_t n, float tmin, float tmax, const StackSpill &spill, bool chain);
 void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,

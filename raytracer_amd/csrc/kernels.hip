@@ -1662,8 +1662,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
 // Closest hits of a batch of rays, one lane per ray, in the loop of k_paths_lanes without the shading: for scenes
 // whose tables are read from HBM (CHAIN: stack traversal over the chain records) or through the L2s (stackless walk).
 // Ray i's hit goes to hits[i]; block b owns the 256-ray chunks b, b + gridDim.x, ...
-template <int K, bool CHAIN>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 4 : 6))) void k_extend_lanes(
+template <int K, bool CHAIN, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CHAIN ? 4 : 6))) void k_extend_lanes(
     SceneDev sc, const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d, float4 *__restrict__ hits, uint32_t n,
     float tmin, float tmax, StackSpill spill) {
     extern __shared__ float4 s_scene[];
@@ -1672,16 +1672,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
     if (threadIdx.x == 0) s_next = 0u;
+    uint32_t chain_lds = kRefNone, root_ref = sc.root_ref;
     if constexpr (!CHAIN) { // the treetop of the walk table
         const uint32_t n4 = sc.top_bytes / 16u;
-        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) s_scene[i] = chain[i];
+        for (uint32_t i = threadIdx.x; i < n4; i += THREADS) s_scene[i] = chain[i];
+    } else if (sc.n_chain_top != 0u) { // the top chain records, behind the stack area
+        float4 *dst = s_scene + (size_t)K * THREADS / 2;
+        const float4 *__restrict__ src = reinterpret_cast<const float4 *>(sc.chain_top);
+        for (uint32_t i = threadIdx.x; i < sc.n_chain_top * 8u; i += THREADS) dst[i] = src[i];
+        chain_lds = lds_address(dst);
+        if ((root_ref & kRefLeaf) == 0u) root_ref = kRefTop; // slot 0 is the root's record
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t chunks = (n + kBlock - 1) / kBlock;
     const uint32_t pool = chunks > blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) * kBlock : 0u;
 
-    typename std::conditional<CHAIN, StackWalk<K, kBlock>, TopWalk>::type walk;
+    typename std::conditional<CHAIN, StackWalk<K, THREADS>, TopWalk>::type walk;
     walk.init(reinterpret_cast<uint2 *>(s_scene), spill);
     uint32_t slot = 0;
     bool have = false, exhausted = false;
@@ -1709,7 +1716,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 
                     const uint32_t item = base + __popcll(empty_mask & ((1ull << lane) - 1ull));
                     slot = ((item / kBlock) * gridDim.x + blockIdx.x) * kBlock + (item % kBlock);
                     if (item < pool && slot < n) {
-                        walk.begin(root_lo, root_hi, sc.root_ref, xyz(ray_o[slot]), xyz(ray_d[slot]), tmin, tmax);
+                        walk.begin(root_lo, root_hi, root_ref, xyz(ray_o[slot]), xyz(ray_d[slot]), tmin, tmax);
                         have = true;
                     }
                 }
@@ -1728,7 +1735,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAIN ? 
                 if (leaf_lane) walk.step_leaf(prims);
             } else {
                 if constexpr (CHAIN) {
-                    if (node_lane) walk.step_node(chain);
+                    if (node_lane) walk.step_node(chain, chain_lds);
                 } else {
                     if (node_lane) walk.step_node(chain, lds_address(s_scene), sc.top_bytes);
                 }
@@ -1831,10 +1838,12 @@ void launch_generate(hipStream_t s, uint32_t max_blocks, const RenderParams &P, 
 void launch_extend_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d, float4 *hits,
                          uint32_t n, float tmin, float tmax, const StackSpill &spill, bool chain) {
     constexpr int K = kStackEntriesInLds;
-    if (chain)
-        hipLaunchKernelGGL((k_extend_lanes<K, true>), dim3(grid), dim3(kBlock), (uint32_t)(K * kBlock * sizeof(uint2)), s, sc, ray_o,
-                           ray_d, hits, n, tmin, tmax, spill);
-    else
+    if (chain) { // one 1024-thread block per CU shares the copy of the top records (see launch_paths_lanes)
+        const uint32_t lds_bytes = (uint32_t)(K * 1024 * sizeof(uint2)) + sc.n_chain_top * (uint32_t)sizeof(ChainNode);
+        auto kernel = k_extend_lanes<K, true, 1024>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), lds_bytes, s, sc, ray_o, ray_d, hits, n, tmin, tmax, spill);
+    } else
         hipLaunchKernelGGL((k_extend_lanes<K, false>), dim3(grid), dim3(kBlock), sc.top_bytes, s, sc, ray_o, ray_d, hits, n, tmin, tmax, spill);
 }
 
