@@ -923,6 +923,9 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     }
     rt::SceneDev dev = s->dev;
     dev.top_bytes = top_bytes;
+    if (lanes_walk && top_bytes == s->dev.n_nodes * (uint32_t)sizeof(rt::WalkNode) &&
+        (uint64_t)top_bytes + (uint64_t)s->dev.n_prims * sizeof(rt::Prim) <= (160u * 1024u) / walk_blocks_per_cu - 2048u)
+        dev.prims_in_lds = 1u;
     const uint32_t cap = ((chunks + grid - 1) / grid) * 256u;
     if (int rc = ensure_render(c, lanes ? 0 : slots, lanes ? 0 : (size_t)grid * cap, st->max_depth, grid)) return rc;
     if (int rc = c->radiance.ensure(slots)) return rc;

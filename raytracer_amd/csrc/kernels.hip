@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
     __shared__ uint32_t s_next, s_rays;
     __shared__ uint32_t s_first[kMaxSegs + 1]; // !FROM_CAMERA: item index of the first entry of each of the block's segments
     const float4 *__restrict__ chain = uniform_pointer(reinterpret_cast<const float4 *>(CHAIN ? static_cast<const void *>(sc.chain) : static_cast<const void *>(sc.walk_nodes)));
-    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
+    const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = reinterpret_cast<const float4 *>(sc.nodes)[0], root_hi = reinterpret_cast<const float4 *>(sc.nodes)[1];
     if (threadIdx.x == 0) {
         s_next = 0u;
@@ -1521,6 +1521,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HAS_MIX
     if constexpr (!CHAIN) { // the treetop of the walk table
         const uint32_t n4 = sc.top_bytes / 16u;
         for (uint32_t i = threadIdx.x; i < n4; i += THREADS) s_scene[i] = chain[i];
+        if (sc.prims_in_lds) { // a scene small enough for its primitives to follow the (whole) node table
+            for (uint32_t i = threadIdx.x; i < 3u * sc.n_prims; i += THREADS) s_scene[n4 + i] = prims[i];
+            prims = s_scene + n4;
+        }
     } else if (sc.n_chain_top != 0u) { // the top chain records, behind the stack area
         float4 *dst = s_scene + (size_t)K * THREADS / 2;
         const float4 *__restrict__ src = reinterpret_cast<const float4 *>(sc.chain_top);
@@ -1973,7 +1977,10 @@ void launch_paths_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const 
         if (sc.top_bytes > 48u * 1024u)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc.top_bytes);
         uint32_t *ray_counts = counts + (size_t)(camera_rays_in_lockstep ? 2u : 1u) * grid;
-        hipLaunchKernelGGL(kernel, dim3(walk_grid), dim3(walk_threads), sc.top_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid,
+        const uint32_t lds_bytes = sc.top_bytes + (sc.prims_in_lds ? sc.n_prims * (uint32_t)sizeof(Prim) : 0u);
+        if (lds_bytes > 48u * 1024u)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kernel, dim3(walk_grid), dim3(walk_threads), lds_bytes, s, sc, P, st, n_slots, cap, queue, counts + grid,
                            ray_counts, spill, grid / walk_grid);
         return;
     }

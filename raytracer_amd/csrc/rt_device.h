@@ -156,6 +156,7 @@ struct SceneDev {
     uint32_t n_chain_top;         // records in chain_top (0: none)
     const WalkNode *walk_nodes;   // n_nodes records, treetop first; nullptr when the table was not built
     uint32_t top_bytes;           // bytes of walk_nodes that form the treetop (a multiple of 32)
+    uint32_t prims_in_lds;        // the lanes kernel also stages the primitive table in LDS, behind the treetop
     uint32_t root_ref;            // child reference of the root (a leaf reference for a one-primitive scene)
     uint32_t depth;               // levels of the tree; the chain walk's stack holds at most 2 entries per interior level
     uint32_t n_nodes;
