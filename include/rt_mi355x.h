@@ -282,8 +282,9 @@ int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
  *   LANES   one lane per PATH: a lane keeps its path in registers until it ends, is shaded where it is when its
  *           walk finishes and takes the next path of its block's share when the path ends; no queues.  Tables above
  *           48 MB are read from HBM: the walk runs over 128-byte records holding up to three levels of child boxes
- *           with a per-lane stack in LDS, from the camera ray on.  Smaller tables sit in the L2s: the stackless walk
- *           over the 32-byte nodes, after bounce 0 has been traced with 64 neighbouring pixels per wave.
+ *           with a per-lane stack in LDS, from the camera ray on, copies of the records nearest the root in LDS.
+ *           Smaller tables sit in the L2s: the stackless walk over 32-byte nodes with explicit successors, the top
+ *           of the tree staged in LDS by every block, after bounce 0 has been traced with 8 x 8 pixels per wave.
  *   AUTO    PATHS_LDS when the tables fit in 150 KB of LDS (256-thread blocks up to 40 KB, above that one
  *           1024-thread block per CU shares the copy), else LANES: the fastest measured on the benchmark scenes.
  *           The other *_LDS pipelines take tables up to 64 KB. */
