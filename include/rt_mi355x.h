@@ -287,7 +287,8 @@ int rt_context_set_max_paths(rt_context *ctx, uint64_t max_paths);
  *           of the tree staged in LDS by every block, after bounce 0 has been traced with 8 x 8 pixels per wave.
  *   AUTO    PATHS_LDS when the tables fit in 150 KB of LDS (256-thread blocks up to 40 KB, above that one
  *           1024-thread block per CU shares the copy), else LANES: the fastest measured on the benchmark scenes.
- *           The other *_LDS pipelines take tables up to 64 KB. */
+ *           The other *_LDS pipelines take tables up to 96 KB.  (Sizes of the LDS copy: 48 bytes per node and per
+ *           primitive.) */
 enum {
     RT_PIPELINE_AUTO = 0,
     RT_PIPELINE_SPLIT = 1,

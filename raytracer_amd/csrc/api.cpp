@@ -105,6 +105,7 @@ struct rt_context {
     // the same for the chain walk (RT_CHAIN_THREADS, RT_CHAIN_TOP_RECORDS)
     uint32_t chain_threads = 0;
     int64_t chain_top_records = -1;
+    int trace_traversal = 0; // RT_TRACE_TRAVERSAL: closest-hit queries by the render kernels' LDS walks (1 sorted, 2 octants)
     float4 *noalloc_scratch = nullptr; // this device's copy of the allocation-free entry point's scratch array
 
     // wavefront workspace
@@ -401,6 +402,7 @@ RT_API int rt_context_create(int device, void *stream, uint32_t flags, rt_contex
         long v = std::strtol(e, nullptr, 10);
         if (v >= 1 && v <= 8) c->walk_blocks_per_cu = (uint32_t)v;
     }
+    if (const char *e = std::getenv("RT_TRACE_TRAVERSAL")) c->trace_traversal = !std::strcmp(e, "sorted") ? 1 : !std::strcmp(e, "octants") ? 2 : 0;
     if (const char *e = std::getenv("RT_CHAIN_THREADS")) {
         long v = std::strtol(e, nullptr, 10);
         if (v == 256 || v == 512 || v == 1024) c->chain_threads = (uint32_t)v;
@@ -713,7 +715,11 @@ RT_API int rt_trace_closest_device(rt_context *c, const rt_scene *s, const rt_ra
     // scene.  The instrumented kernel and the scan of the object list keep the lockstep kernel.
     const uint64_t table_bytes = (uint64_t)s->dev.n_nodes * sizeof(rt::Node) + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
     const bool lanes = use_bvh && !count && (c->lanes_traversal != 0 || table_bytes > kTraceLanesBytes);
-    if (lanes) {
+    if (use_bvh && c->trace_traversal &&
+        rt::launch_extend_plain(c->stream, grid, s->dev, c->ray_o.ptr, c->ray_d.ptr, c->hit.ptr, (uint32_t)n, t_min, t_max,
+                                count ? c->counters.ptr : nullptr, c->trace_traversal == 2)) {
+        // the render kernels' walks, on request (a scene whose copy does not fit LDS falls through to the usual kernels)
+    } else if (lanes) {
         const bool chain = s->dev.n_prims <= rt::kRefIndex && (c->lanes_traversal > 0 || (c->lanes_traversal == 0 && table_bytes > (2u << 20)));
         if (int rc = chain ? ensure_chain(c, s) : ensure_walk(c, s)) return rc;
         // chain: one 1024-thread block per CU (16 waves: four per SIMD), else six 256-thread blocks
@@ -844,7 +850,9 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     // bounce 0 runs in lockstep first (neighbouring pixels share their nodes) and lanes take over the survivors
     // (teapot 6.7 vs 4.9 lit and 3.7 vs 2.5 with the default camera, 300 k soup 1.66 vs 1.46; small soups lose a
     // little: 100 k 3.6 vs 3.74, 30 k 7.25 vs 7.5).
-    if (pipeline == RT_PIPELINE_AUTO) pipeline = table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_LANES;
+    // (the fused kernels' LDS copy stores a node in 48 bytes, see stage_scene_sorted)
+    const uint64_t lds_table_bytes = (uint64_t)s->dev.n_nodes * 48u + (uint64_t)s->dev.n_prims * sizeof(rt::Prim);
+    if (pipeline == RT_PIPELINE_AUTO) pipeline = lds_table_bytes <= 150u * 1024u ? RT_PIPELINE_PATHS_LDS : RT_PIPELINE_LANES;
     bool lds = pipeline == RT_PIPELINE_FUSED_LDS || pipeline == RT_PIPELINE_HYBRID_LDS || pipeline == RT_PIPELINE_SPLIT_LDS ||
                pipeline == RT_PIPELINE_PATHS_LDS;
     if (count) {
@@ -860,10 +868,10 @@ RT_API int rt_render_device(rt_context *c, const rt_scene *s, const rt_camera *c
     const int lanes_waves = s->has_mix ? 4 : c->lanes_waves ? c->lanes_waves : (lanes_chain ? 4 : 6);
     if (s->has_mix && pipeline != RT_PIPELINE_PATHS && pipeline != RT_PIPELINE_PATHS_LDS && !lanes)
         pipeline = lds ? RT_PIPELINE_SPLIT_LDS : RT_PIPELINE_SPLIT;
-    const bool big_blocks = pipeline == RT_PIPELINE_PATHS_LDS && table_bytes > 40u * 1024u;
-    if (lds && table_bytes > (big_blocks ? 150u : 64u) * 1024u)
+    const bool big_blocks = pipeline == RT_PIPELINE_PATHS_LDS && lds_table_bytes > 40u * 1024u;
+    if (lds && lds_table_bytes > (big_blocks ? 150u : 96u) * 1024u)
         return set_error(RT_ERR_INVALID_ARGUMENT, "scene tables (%llu bytes) do not fit the LDS pipeline",
-                         (unsigned long long)table_bytes);
+                         (unsigned long long)lds_table_bytes);
     const bool paths = pipeline == RT_PIPELINE_PATHS || pipeline == RT_PIPELINE_PATHS_LDS || lanes;
     const bool fused_all = paths || pipeline == RT_PIPELINE_FUSED || pipeline == RT_PIPELINE_FUSED_LDS;
     const bool fused_first = fused_all || pipeline == RT_PIPELINE_HYBRID || pipeline == RT_PIPELINE_HYBRID_LDS;

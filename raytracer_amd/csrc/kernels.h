@@ -22,6 +22,11 @@ void launch_extend_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const
 void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
                    float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters,
                    uint32_t lds_bytes);
+// Closest hits of rays [0, n) by the fused render kernels' walks over their LDS copies of the scene (48-byte sorted
+// nodes, or eight copies per node when `octants`), counting box and primitive tests into `counters` when given: a
+// test vehicle for those walks.  False (nothing launched) when the copy does not fit 150 KB of LDS.
+bool launch_extend_plain(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d, float4 *hits,
+                         uint32_t n, float tmin, float tmax, ExtendCounters *counters, bool octants);
 
 // Shades the items of `q`; block b appends its surviving slots at queue_out[b * q.cap ...], stores their
 // number in counts_out[b] and in early_out[b] the number of paths it ended because their next ray misses the

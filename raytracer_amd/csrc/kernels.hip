@@ -282,6 +282,132 @@ __device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, co
     return best;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The walk over tables in LDS with the slabs ordered by the sign of the direction.
+//
+// For a positive reciprocal the distance to an axis' low plane is the smaller of the two (subtraction and
+// multiplication round monotonically and low <= high), for a negative one the distance to the high plane: which of the
+// two distances is the entry is known per ray, and no instruction has to order them per box.  The LDS copy stores an
+// axis as (low, high, low), so that the pair read at byte offset 0 is (low, high) and the pair at offset 4 is (high,
+// low): a per-ray offset per axis delivers (entry plane, exit plane) directly, and the interval update is
+// lo = max(lo, entries), hi = min(hi, exits) with NaN operands dropped, which is what Aabb::hit's compare-and-assign
+// does with a NaN.  4 min / max per box test instead of 10 (or a compare and two selects per axis as written).
+//
+// Where that differs from Aabb::hit (src/aabb.rs:95-127): only when exactly one of an axis' two distances is a NaN,
+// i.e. (for coordinates below 1.7e38) a direction component of +0 or -0 with the origin exactly on one of the planes.
+// Aabb::hit then passes the axis for -0 iff low <= origin <= high and for +0 iff low < origin < high (a NaN makes
+// `t0 < t1` false, and the else-branch assigns the infinity of the other plane to one bound or leaves both alone).
+// Here both zeros get the reciprocal +inf, so entry = (low - o) * inf is -inf (no constraint) for low < o, NaN
+// (dropped: no constraint) for low == o and +inf (reject) for low > o, and likewise the exit: that IS the rule for
+// -0.  For +0 the origin is replaced by its lower binary32 neighbour for the low plane and its upper neighbour for the
+// high plane, which turns `<=` into `<`: low - down(o) <= 0 iff low < o.  NaN and infinite origins behave as in
+// Aabb::hit (both distances NaN: axis passed; both the same infinity: rejected).
+// ------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSortedNodeBytes = 48u; // (xlo xhi xlo) (ylo yhi ylo) (zlo zhi zlo) skip leaf pad
+
+struct SortedSlabs {
+    v2f ox, oy, oz;        // origin for the (entry, exit) plane of each axis
+    V3 inv;
+    uint32_t ax, ay, az;   // byte offset of an axis' (entry, exit) pair within a node
+};
+
+__device__ __forceinline__ void sorted_axis(float o, float d, uint32_t base, v2f &origin, float &inv, uint32_t &at) {
+    inv = 1.0f / d;
+    origin = v2f{o, o};
+    at = base;
+    if (d == 0.0f) { // either zero
+        inv = __builtin_inff();
+        if (f2u(d) == 0u) origin = v2f{next_down(o), next_up(o)};
+    } else if (inv < 0.0f) {
+        at = base + 4u;
+    }
+}
+
+__device__ __forceinline__ SortedSlabs make_sorted_slabs(V3 o, V3 d) {
+    SortedSlabs s;
+    sorted_axis(o.x, d.x, 0u, s.ox, s.inv.x, s.ax);
+    sorted_axis(o.y, d.y, 12u, s.oy, s.inv.y, s.ay);
+    sorted_axis(o.z, d.z, 24u, s.oz, s.inv.z, s.az);
+    return s;
+}
+
+// BvhNode::hit as the stackless pre-order walk (traverse()) over the sorted LDS copy: `nodes` is the copy, skip links
+// are byte offsets into it.
+template <bool COUNT = false>
+__device__ __forceinline__ Closest traverse_sorted(const char *nodes, const float4 *__restrict__ prims, uint32_t n_nodes, V3 o,
+                                                   V3 d, float tmin, float tmax, uint32_t *visits = nullptr) {
+    const SortedSlabs r = make_sorted_slabs(o, d);
+    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    tmin = in_vgpr(tmin);
+    uint32_t cur = 0;
+    const uint32_t end = n_nodes * kSortedNodeBytes;
+    while (cur < end) {
+        const float *px = reinterpret_cast<const float *>(nodes + cur + r.ax);
+        const float *py = reinterpret_cast<const float *>(nodes + cur + r.ay);
+        const float *pz = reinterpret_cast<const float *>(nodes + cur + r.az);
+        const uint32_t *links = reinterpret_cast<const uint32_t *>(nodes + cur + 36u);
+        const v2f tx = (v2f{px[0], px[1]} - r.ox) * v2f{r.inv.x, r.inv.x};
+        const v2f ty = (v2f{py[0], py[1]} - r.oy) * v2f{r.inv.y, r.inv.y};
+        const v2f tz = (v2f{pz[0], pz[1]} - r.oz) * v2f{r.inv.z, r.inv.z};
+        const uint32_t skip = links[0], leaf = links[1];
+        const float lo = max_raw(max3_raw(tmin, tx.x, ty.x), tz.x);
+        const float hi = min_raw(min3_raw(best.t, tx.y, ty.y), tz.y);
+        const bool hit = !(hi <= lo);
+        if (COUNT) ++visits[0];
+        if (hit && leaf != kInterior) {
+            const uint32_t slot = leaf & ~kSphereBit;
+            if (COUNT) ++visits[(leaf & kSphereBit) ? 2 : 1];
+            if (leaf & kSphereBit)
+                sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+            else
+                tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+        }
+        cur = hit ? cur + kSortedNodeBytes : skip;
+    }
+    return best;
+}
+
+// The same walk for scenes of a few dozen nodes: the LDS copy holds every node eight times, once per combination of
+// direction signs, each copy with its planes already in (entry, exit) order and with its own skip link, all as absolute
+// LDS addresses.  A ray picks its copy once (32 bytes per copy, 256 per node) and a box test needs no address
+// arithmetic at all: two 16-byte reads, six packed operations, four min / max.
+constexpr uint32_t kOctantNodeBytes = 256u;
+
+template <bool COUNT = false>
+__device__ __forceinline__ Closest traverse_octants(uint32_t lds_nodes, const float4 *__restrict__ prims, uint32_t n_nodes, V3 o, V3 d,
+                                                    float tmin, float tmax, uint32_t *visits = nullptr) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4f LdsF4;
+    const SortedSlabs r = make_sorted_slabs(o, d);
+    Closest best{tmax, kMissSlot, 0.0f, 0.0f};
+    tmin = in_vgpr(tmin);
+    // the copy for this ray's signs: x reversed -> + 32, y -> + 64, z -> + 128 (ax, ay, az are 4 above their axis' base then)
+    uint32_t cur = lds_nodes + (r.ax << 3) + ((r.ay - 12u) << 4) + ((r.az - 24u) << 5);
+    const uint32_t end = lds_nodes + n_nodes * kOctantNodeBytes;
+    while (cur < end) {
+        LdsF4 *node = reinterpret_cast<LdsF4 *>((uintptr_t)cur);
+        const v4f a = node[0], b = node[1];
+        const v2f tx = (v2f{a.x, a.y} - r.ox) * v2f{r.inv.x, r.inv.x};
+        const v2f ty = (v2f{a.z, a.w} - r.oy) * v2f{r.inv.y, r.inv.y};
+        const v2f tz = (v2f{b.x, b.y} - r.oz) * v2f{r.inv.z, r.inv.z};
+        const uint32_t skip = f2u(b.z), leaf = f2u(b.w);
+        const float lo = max_raw(max3_raw(tmin, tx.x, ty.x), tz.x);
+        const float hi = min_raw(min3_raw(best.t, tx.y, ty.y), tz.y);
+        const bool hit = !(hi <= lo);
+        if (COUNT) ++visits[0];
+        if (hit && leaf != kInterior) {
+            const uint32_t slot = leaf & ~kSphereBit;
+            if (COUNT) ++visits[(leaf & kSphereBit) ? 2 : 1];
+            if (leaf & kSphereBit)
+                sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+            else
+                tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
+        }
+        cur = hit ? cur + kOctantNodeBytes : skip;
+    }
+    return best;
+}
+
 // World::hit (src/object/world.rs:21-39): every object in list order with a shrinking max.
 __device__ __forceinline__ Closest scan_world(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax) {
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(sc.prims);
@@ -1005,6 +1131,38 @@ __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *l
     prims = lds + n4_nodes;
 }
 
+// The same for traverse_sorted: nodes as 48-byte records (an axis as low, high, low; skip as a byte offset), primitives
+// behind them.  `nodes` comes back as the byte address of the copy.
+__device__ __forceinline__ void stage_scene_sorted(const SceneDev &sc, float4 *lds, const float4 *nodes, const char *&lds_nodes,
+                                                   const float4 *&prims) {
+    const uint32_t n4_nodes = 3u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
+    for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += blockDim.x) {
+        const float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+        lds[3 * i] = make_float4(a.x, a.y, a.x, a.z);
+        lds[3 * i + 1] = make_float4(a.w, a.z, b.x, b.y);
+        lds[3 * i + 2] = make_float4(b.x, u2f(f2u(b.z) * kSortedNodeBytes), b.w, 0.0f);
+    }
+    for (uint32_t i = threadIdx.x; i < n4_prims; i += blockDim.x) lds[n4_nodes + i] = prims[i];
+    lds_nodes = reinterpret_cast<const char *>(lds);
+    prims = lds + n4_nodes;
+}
+
+// The same for traverse_octants: eight copies of every node (copy c: x reversed when c & 1, y when c & 2, z when c & 4),
+// skip links as absolute LDS addresses of the same copy of the target.  Returns the LDS address of the copy.
+__device__ __forceinline__ uint32_t stage_scene_octants(const SceneDev &sc, float4 *lds, const float4 *nodes, const float4 *&prims) {
+    const uint32_t n4_nodes = 16u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
+    const uint32_t base = lds_address(lds);
+    for (uint32_t i = threadIdx.x; i < 8u * sc.n_nodes; i += blockDim.x) {
+        const uint32_t node = i >> 3, c = i & 7u;
+        const float4 a = nodes[2 * node], b = nodes[2 * node + 1];
+        lds[2 * i] = make_float4((c & 1u) ? a.y : a.x, (c & 1u) ? a.x : a.y, (c & 2u) ? a.w : a.z, (c & 2u) ? a.z : a.w);
+        lds[2 * i + 1] = make_float4((c & 4u) ? b.y : b.x, (c & 4u) ? b.x : b.y, u2f(base + f2u(b.z) * kOctantNodeBytes + c * 32u), b.w);
+    }
+    for (uint32_t i = threadIdx.x; i < n4_prims; i += blockDim.x) lds[n4_nodes + i] = prims[i];
+    prims = lds + n4_nodes;
+    return base;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // extend: closest hit of every queued ray.
 //
@@ -1147,6 +1305,38 @@ __global__ __launch_bounds__(kBlock) void k_extend_world(SceneDev sc, const floa
         uint32_t slot = c.ident ? i : q.items[c.seg + i];
         Closest best = scan_world(sc, xyz(ray_o[slot]), xyz(ray_d[slot]), tmin, tmax);
         hits[slot] = make_float4(best.t, u2f(best.slot), best.u, best.v);
+    }
+}
+
+// Closest hits by the walks of the fused render kernels over their LDS copies (traverse_sorted: SORTED = true,
+// traverse_octants: false), one ray per lane, with the box and primitive tests counted: rt_trace_closest runs it when asked
+// to (RT_TRACE_TRAVERSAL), so that those walks can be driven with chosen rays and their box decisions compared with the
+// oracle's visit counts.
+template <bool SORTED>
+__global__ __launch_bounds__(kBlock) void k_extend_plain(SceneDev sc, const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
+                                                         float4 *__restrict__ hits, uint32_t n, float tmin, float tmax,
+                                                         ExtendCounters *counters) {
+    extern __shared__ float4 s_scene[];
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
+    const char *sorted_nodes = nullptr;
+    uint32_t octant_nodes = 0;
+    if (SORTED)
+        stage_scene_sorted(sc, s_scene, nodes, sorted_nodes, prims);
+    else
+        octant_nodes = stage_scene_octants(sc, s_scene, nodes, prims);
+    __syncthreads();
+    uint32_t visits[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const V3 o = xyz(ray_o[i]), d = xyz(ray_d[i]);
+        const Closest best = SORTED ? traverse_sorted<true>(sorted_nodes, prims, sc.n_nodes, o, d, tmin, tmax, visits)
+                                    : traverse_octants<true>(octant_nodes, prims, sc.n_nodes, o, d, tmin, tmax, visits);
+        hits[i] = make_float4(best.t, u2f(best.slot), best.u, best.v);
+    }
+    if (counters) {
+        if (visits[0]) atomicAdd(&counters->node_visits, (unsigned long long)visits[0]);
+        if (visits[1]) atomicAdd(&counters->triangle_tests, (unsigned long long)visits[1]);
+        if (visits[2]) atomicAdd(&counters->sphere_tests, (unsigned long long)visits[2]);
     }
 }
 
@@ -1315,7 +1505,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = nodes[0], root_hi = nodes[1]; // the root box in the table's own layout, for early misses
-    if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
+    const char *sorted_nodes = nullptr;
+    if (LDS_SCENE) stage_scene_sorted(sc, s_scene, nodes, sorted_nodes, prims);
     const float4 *__restrict__ walk_nodes = nullptr;
     if constexpr (STACK < 0) {
         walk_nodes = uniform_pointer(reinterpret_cast<const float4 *>(sc.walk_nodes));
@@ -1361,8 +1552,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
             } else if constexpr (STACK < 0) {
                 best = traverse_walk(walk_nodes, lds_address(s_scene), sc.top_bytes, prims, o, d, P.z_near, P.z_far);
             } else {
-                uint32_t c0 = 0, c1 = 0, c2 = 0;
-                best = traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+                if constexpr (LDS_SCENE) {
+                    best = traverse_sorted(sorted_nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far);
+                } else {
+                    uint32_t c0 = 0, c1 = 0, c2 = 0;
+                    best = traverse<false, false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+                }
             }
             alive = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
         }
@@ -1387,7 +1582,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
 // WAVES: waves per SIMD the register budget is set for.  Six fit without spilling and suit scenes served by LDS
 // or the caches; scenes read from HBM gain more from eight waves in flight than the few spilled registers cost.
 // HAS_MIX: the scene holds Mix materials (evaluated by scatter_material instead of scatter_leaf).
-template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false>
+// OCTANTS: the LDS copy holds eight copies of every node (traverse_octants; scenes of a few dozen nodes).
+template <bool LDS_SCENE, bool NEED_UV, int THREADS = kBlock, int WAVES = 6, bool HAS_MIX = false, bool OCTANTS = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREADS == kBlock && !HAS_MIX) ? WAVES : 4))) void k_paths(
     SceneDev sc, RenderParams P, PathState st, uint32_t n_slots, uint32_t cap, uint32_t *__restrict__ queue0,
     uint32_t *__restrict__ queue1, uint32_t *__restrict__ counts, uint32_t *__restrict__ early) {
@@ -1396,10 +1592,23 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = nodes[0], root_hi = nodes[1];
-    if (LDS_SCENE) stage_scene_in_lds(sc, s_scene, nodes, prims);
+    const char *sorted_nodes = nullptr;
+    uint32_t octant_nodes = 0;
+    if constexpr (LDS_SCENE) {
+        if constexpr (OCTANTS)
+            octant_nodes = stage_scene_octants(sc, s_scene, nodes, prims);
+        else
+            stage_scene_sorted(sc, s_scene, nodes, sorted_nodes, prims);
+    }
     auto closest_hit = [&](V3 o, V3 d) {
-        uint32_t c0 = 0, c1 = 0, c2 = 0;
-        return traverse<false, LDS_SCENE>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+        if constexpr (LDS_SCENE && OCTANTS) {
+            return traverse_octants(octant_nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far);
+        } else if constexpr (LDS_SCENE) {
+            return traverse_sorted(sorted_nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far);
+        } else {
+            uint32_t c0 = 0, c1 = 0, c2 = 0;
+            return traverse<false, false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+        }
     };
     if (threadIdx.x == 0) {
         s_out = 0u;
@@ -1851,10 +2060,25 @@ void launch_extend_lanes(hipStream_t s, uint32_t grid, const SceneDev &sc, const
         hipLaunchKernelGGL((k_extend_lanes<K, false>), dim3(grid), dim3(kBlock), sc.top_bytes, s, sc, ray_o, ray_d, hits, n, tmin, tmax, spill);
 }
 
+bool launch_extend_plain(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d, float4 *hits,
+                         uint32_t n, float tmin, float tmax, ExtendCounters *counters, bool octants) {
+    const uint32_t lds_bytes = sc.n_nodes * (octants ? kOctantNodeBytes : kSortedNodeBytes) + sc.n_prims * (uint32_t)sizeof(Prim);
+    if (lds_bytes > 150u * 1024u) return false;
+    auto kernel = octants ? k_extend_plain<false> : k_extend_plain<true>;
+    if (lds_bytes > 48u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, s, sc, ray_o, ray_d, hits, n, tmin, tmax, counters);
+    return true;
+}
+
 void launch_extend(hipStream_t s, uint32_t grid, const SceneDev &sc, const float4 *ray_o, const float4 *ray_d,
                    float4 *hits, const QueueView &q, float tmin, float tmax, bool use_bvh, ExtendCounters *counters,
                    uint32_t lds_bytes) {
     dim3 g(grid), b(kBlock);
+    if (lds_bytes > 48u * 1024u) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    }
     if (!use_bvh)
         hipLaunchKernelGGL(k_extend_world, g, b, 0, s, sc, ray_o, ray_d, hits, q, tmin, tmax);
     else if (counters && lds_bytes)
@@ -1885,10 +2109,11 @@ static void launch_bounce_t(hipStream_t s, uint32_t grid, const SceneDev &sc, co
                             bool need_uv, uint32_t lds_bytes) {
     dim3 g(grid), b(kBlock);
     if (lds_bytes) {
-        if (need_uv)
-            hipLaunchKernelGGL((k_bounce<FIRST, true, true>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
-        else
-            hipLaunchKernelGGL((k_bounce<FIRST, true, false>), g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
+        lds_bytes = sc.n_nodes * kSortedNodeBytes + sc.n_prims * (uint32_t)sizeof(Prim); // the sorted copy (stage_scene_sorted)
+        auto kernel = need_uv ? k_bounce<FIRST, true, true> : k_bounce<FIRST, true, false>;
+        if (lds_bytes > 48u * 1024u)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kernel, g, b, lds_bytes, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
     } else {
         if (need_uv)
             hipLaunchKernelGGL((k_bounce<FIRST, false, true>), g, b, 0, s, sc, P, st, q, queue_out, counts_out, early_out, StackSpill{});
@@ -1912,8 +2137,14 @@ void launch_paths(hipStream_t s, uint32_t grid, const SceneDev &sc, const Render
     using Kernel = void (*)(SceneDev, RenderParams, PathState, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *);
     Kernel kernel;
     uint32_t threads = kBlock;
+    if (lds_bytes) lds_bytes = sc.n_nodes * kSortedNodeBytes + sc.n_prims * (uint32_t)sizeof(Prim); // the sorted copy (stage_scene_sorted)
+    // Tiny scenes (Cornell: 71 nodes, 20 KB): eight copies per node, as long as six 256-thread blocks still fit a CU.
+    const uint32_t octant_bytes = sc.n_nodes * kOctantNodeBytes + sc.n_prims * (uint32_t)sizeof(Prim);
     // Scenes with Mix materials use the instances that also interpolate texture coordinates.
-    if (!lds_bytes && eight_waves) {
+    if (lds_bytes && !big_blocks && !has_mix && octant_bytes <= 24u * 1024u) {
+        kernel = need_uv ? k_paths<true, true, kBlock, 6, false, true> : k_paths<true, false, kBlock, 6, false, true>;
+        lds_bytes = octant_bytes;
+    } else if (!lds_bytes && eight_waves) {
         kernel = has_mix ? k_paths<false, true, kBlock, 8, true> : need_uv ? k_paths<false, true, kBlock, 8> : k_paths<false, false, kBlock, 8>;
     } else if (lds_bytes && big_blocks) {
         kernel = has_mix ? k_paths<true, true, 1024, 6, true> : need_uv ? k_paths<true, true, 1024> : k_paths<true, false, 1024>;

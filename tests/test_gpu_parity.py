@@ -41,7 +41,7 @@ def assert_images_equal(gpu, cpu, min_agree=1.0):
 
 
 @pytest.mark.parametrize("name", ["cornell", "teapot", "rtiow"])
-def test_signed_zero_directions_with_origins_on_box_planes(cornell, teapot, name):
+def test_signed_zero_directions_with_origins_on_box_planes(cornell, teapot, name, monkeypatch):
     """Aabb::hit (src/aabb.rs:95-127) with a direction component of exactly +0 or -0 and the origin exactly on, one
     binary32 below and one above a plane of a node's box: 1 / +0 = +inf, 1 / -0 = -inf and (plane - origin) * inf is a
     NaN on the plane itself, which compare-and-assign treats differently for the two signs (with -0 a box is passed by an
@@ -95,6 +95,22 @@ def test_signed_zero_directions_with_origins_on_box_planes(cornell, teapot, name
     plain.close()
     g.close()
     ctx.close()
+    # ... and through the walks of the fused render kernels over their LDS copies, which order the slabs by the sign of
+    # the direction instead (48-byte nodes; eight copies per node for scenes as small as Cornell): hits and visit counts
+    for walk in ("sorted", "octants"):
+        if walk == "octants" and name != "cornell":
+            continue  # eight copies of these trees do not fit LDS
+        monkeypatch.setenv("RT_TRACE_TRAVERSAL", walk)
+        ctx3 = Context(0, flags=F.RT_CTX_COUNTERS)
+        g3 = Scene(ctx3, desc)
+        for t_min, t_max in ((1e-4, np.inf), (-1.0, 50.0)):
+            got, gst = g3.trace_closest(arr, t_min, t_max)
+            want, ost = o.trace_closest(arr, t_min, t_max)
+            assert_hits_equal(got, want)
+            assert (gst.node_visits, gst.triangle_tests, gst.sphere_tests) == (ost.node_visits, ost.triangle_tests, ost.sphere_tests), walk
+        g3.close()
+        ctx3.close()
+        monkeypatch.delenv("RT_TRACE_TRAVERSAL")
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -412,9 +428,10 @@ def test_lanes_pipeline_variants(cornell, teapot, monkeypatch, traversal, first)
 
 
 def test_mid_size_scene_uses_the_shared_lds_copy(gpu_ctx):
-    """Scene tables between 40 and 150 KB (here 1200 triangles = 134 KB, and the 485 spheres = 54 KB) are staged
-    in LDS once per 1024-thread block by the default pipeline; sums and ray counts equal the oracle's."""
-    for desc, cs, bg in ((triangle_soup(1200, emissive_fraction=0.05) + ((0.3, 0.4, 0.5),)), (rtiow_final_scene() + ((0.7, 0.8, 1.0),))):
+    """Scene tables whose LDS copy (48 bytes per node and per primitive) takes between 40 and 150 KB (here 1000
+    triangles = 141 KB, and the 485 spheres = 68 KB) are staged in LDS once per 1024-thread block by the default
+    pipeline; sums and ray counts equal the oracle's."""
+    for desc, cs, bg in ((triangle_soup(1000, emissive_fraction=0.05) + ((0.3, 0.4, 0.5),)), (rtiow_final_scene() + ((0.7, 0.8, 1.0),))):
         rs = RenderSettings(200, 120, 0, 20, 5, mode=F.RT_MODE_LINEAR_MEAN, seed=8, background_color=bg)
         gpu, cpu, gst, cst = render_pair(gpu_ctx, desc, cs, rs)
         assert_images_equal(gpu, cpu)
@@ -452,7 +469,7 @@ def test_mix_materials(gpu_ctx, cornell):
         assert gst.rays_traced == cst.rays_traced and gst.pipeline == ran
         ctx.close()
     # a Mix scene too large for one 256-thread block's LDS: the 1024-thread and the HBM instances
-    big, cs = triangle_soup(1200, emissive_fraction=0.05)
+    big, cs = triangle_soup(1000, emissive_fraction=0.05)
     lam, met = big.lambertian((0.8, 0.7, 0.6)), big.metal((0.9, 0.9, 0.9), 0.2)
     mixed = big.mix(lam, met, 0.4)
     big.meshes[0] = TriangleMesh(big.meshes[0].positions, big.meshes[0].indices, big.meshes[0].normals, big.meshes[0].uvs, mixed)
