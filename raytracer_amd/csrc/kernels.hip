@@ -331,25 +331,26 @@ __device__ __forceinline__ SortedSlabs make_sorted_slabs(V3 o, V3 d) {
     return s;
 }
 
-// BvhNode::hit as the stackless pre-order walk (traverse()) over the sorted LDS copy: `nodes` is the copy, skip links
-// are byte offsets into it.
+// BvhNode::hit as the stackless pre-order walk (traverse()) over the sorted LDS copy at LDS address `lds_nodes`.
 template <bool COUNT = false>
-__device__ __forceinline__ Closest traverse_sorted(const char *nodes, const float4 *__restrict__ prims, uint32_t n_nodes, V3 o,
+__device__ __forceinline__ Closest traverse_sorted(uint32_t lds_nodes, const float4 *__restrict__ prims, uint32_t n_nodes, V3 o,
                                                    V3 d, float tmin, float tmax, uint32_t *visits = nullptr) {
+    typedef __attribute__((address_space(3))) const float LdsF;
+    typedef __attribute__((address_space(3))) const uint32_t LdsU;
     const SortedSlabs r = make_sorted_slabs(o, d);
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
     tmin = in_vgpr(tmin);
-    uint32_t cur = 0;
-    const uint32_t end = n_nodes * kSortedNodeBytes;
+    uint32_t cur = lds_nodes; // LDS addresses throughout: the copy's skip links are absolute too
+    const uint32_t end = lds_nodes + n_nodes * kSortedNodeBytes;
     while (cur < end) {
-        const float *px = reinterpret_cast<const float *>(nodes + cur + r.ax);
-        const float *py = reinterpret_cast<const float *>(nodes + cur + r.ay);
-        const float *pz = reinterpret_cast<const float *>(nodes + cur + r.az);
-        const uint32_t *links = reinterpret_cast<const uint32_t *>(nodes + cur + 36u);
+        LdsF *px = reinterpret_cast<LdsF *>((uintptr_t)(cur + r.ax));
+        LdsF *py = reinterpret_cast<LdsF *>((uintptr_t)(cur + r.ay));
+        LdsF *pz = reinterpret_cast<LdsF *>((uintptr_t)(cur + r.az));
+        LdsU *links = reinterpret_cast<LdsU *>((uintptr_t)cur);
         const v2f tx = (v2f{px[0], px[1]} - r.ox) * v2f{r.inv.x, r.inv.x};
         const v2f ty = (v2f{py[0], py[1]} - r.oy) * v2f{r.inv.y, r.inv.y};
         const v2f tz = (v2f{pz[0], pz[1]} - r.oz) * v2f{r.inv.z, r.inv.z};
-        const uint32_t skip = links[0], leaf = links[1];
+        const uint32_t skip = links[9], leaf = links[10];
         const float lo = max_raw(max3_raw(tmin, tx.x, ty.x), tz.x);
         const float hi = min_raw(min3_raw(best.t, tx.y, ty.y), tz.y);
         const bool hit = !(hi <= lo);
@@ -1131,20 +1132,20 @@ __device__ __forceinline__ void stage_scene_in_lds(const SceneDev &sc, float4 *l
     prims = lds + n4_nodes;
 }
 
-// The same for traverse_sorted: nodes as 48-byte records (an axis as low, high, low; skip as a byte offset), primitives
-// behind them.  `nodes` comes back as the byte address of the copy.
-__device__ __forceinline__ void stage_scene_sorted(const SceneDev &sc, float4 *lds, const float4 *nodes, const char *&lds_nodes,
-                                                   const float4 *&prims) {
+// The same for traverse_sorted: nodes as 48-byte records (an axis as low, high, low; skip as the absolute LDS address of
+// its target), primitives behind them.  Returns the LDS address of the copy.
+__device__ __forceinline__ uint32_t stage_scene_sorted(const SceneDev &sc, float4 *lds, const float4 *nodes, const float4 *&prims) {
     const uint32_t n4_nodes = 3u * sc.n_nodes, n4_prims = 3u * sc.n_prims;
+    const uint32_t base = lds_address(lds);
     for (uint32_t i = threadIdx.x; i < sc.n_nodes; i += blockDim.x) {
         const float4 a = nodes[2 * i], b = nodes[2 * i + 1];
         lds[3 * i] = make_float4(a.x, a.y, a.x, a.z);
         lds[3 * i + 1] = make_float4(a.w, a.z, b.x, b.y);
-        lds[3 * i + 2] = make_float4(b.x, u2f(f2u(b.z) * kSortedNodeBytes), b.w, 0.0f);
+        lds[3 * i + 2] = make_float4(b.x, u2f(base + f2u(b.z) * kSortedNodeBytes), b.w, 0.0f);
     }
     for (uint32_t i = threadIdx.x; i < n4_prims; i += blockDim.x) lds[n4_nodes + i] = prims[i];
-    lds_nodes = reinterpret_cast<const char *>(lds);
     prims = lds + n4_nodes;
+    return base;
 }
 
 // The same for traverse_octants: eight copies of every node (copy c: x reversed when c & 1, y when c & 2, z when c & 4),
@@ -1319,10 +1320,9 @@ __global__ __launch_bounds__(kBlock) void k_extend_plain(SceneDev sc, const floa
     extern __shared__ float4 s_scene[];
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
-    const char *sorted_nodes = nullptr;
-    uint32_t octant_nodes = 0;
+    uint32_t sorted_nodes = 0, octant_nodes = 0;
     if (SORTED)
-        stage_scene_sorted(sc, s_scene, nodes, sorted_nodes, prims);
+        sorted_nodes = stage_scene_sorted(sc, s_scene, nodes, prims);
     else
         octant_nodes = stage_scene_octants(sc, s_scene, nodes, prims);
     __syncthreads();
@@ -1505,8 +1505,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = nodes[0], root_hi = nodes[1]; // the root box in the table's own layout, for early misses
-    const char *sorted_nodes = nullptr;
-    if (LDS_SCENE) stage_scene_sorted(sc, s_scene, nodes, sorted_nodes, prims);
+    uint32_t sorted_nodes = 0;
+    if (LDS_SCENE) sorted_nodes = stage_scene_sorted(sc, s_scene, nodes, prims);
     const float4 *__restrict__ walk_nodes = nullptr;
     if constexpr (STACK < 0) {
         walk_nodes = uniform_pointer(reinterpret_cast<const float4 *>(sc.walk_nodes));
@@ -1592,13 +1592,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims = reinterpret_cast<const float4 *>(sc.prims);
     const float4 root_lo = nodes[0], root_hi = nodes[1];
-    const char *sorted_nodes = nullptr;
-    uint32_t octant_nodes = 0;
+    uint32_t sorted_nodes = 0, octant_nodes = 0;
     if constexpr (LDS_SCENE) {
         if constexpr (OCTANTS)
             octant_nodes = stage_scene_octants(sc, s_scene, nodes, prims);
         else
-            stage_scene_sorted(sc, s_scene, nodes, sorted_nodes, prims);
+            sorted_nodes = stage_scene_sorted(sc, s_scene, nodes, prims);
     }
     auto closest_hit = [&](V3 o, V3 d) {
         if constexpr (LDS_SCENE && OCTANTS) {

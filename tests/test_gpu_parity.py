@@ -738,6 +738,27 @@ def test_render_edge_cases(gpu_ctx, cornell):
         assert r.last_stats.rays_traced == cst.rays_traced
 
 
+def test_degenerate_trees_through_the_lds_pipelines():
+    """Scenes of one and two primitives (the root is a leaf / the only interior node) through the pipelines that walk an
+    LDS copy of the tree (eight copies per node, 48-byte sorted nodes, the split kernels' 32-byte nodes) and AUTO."""
+    from raytracer_amd.scene import CameraSettings
+
+    one = SceneDescription()
+    one.meshes.append(TriangleMesh(np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32),
+                                   np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), one.lambertian((0.5, 0.6, 0.7))))
+    two = SceneDescription(list(one.meshes), [Sphere((0.0, 0.0, -1.0), 0.5, 0)], list(one.materials), list(one.textures))
+    cs = CameraSettings.look_at((0.0, 0.0, 3.0), (0.0, 0.0, 0.0), 50.0, z_near=1e-3)
+    rs = RenderSettings(48, 40, 0, 8, 3, mode=F.RT_MODE_LINEAR_MEAN, seed=31, background_color=(0.3, 0.2, 0.1))
+    for pipeline in (F.RT_PIPELINE_AUTO, F.RT_PIPELINE_PATHS_LDS, F.RT_PIPELINE_FUSED_LDS, F.RT_PIPELINE_SPLIT_LDS):
+        ctx = Context(0)
+        ctx.set_pipeline(pipeline)
+        for desc in (one, two):
+            gpu, cpu, gst, cst = render_pair(ctx, desc, cs, rs)
+            assert_images_equal(gpu, cpu)
+            assert gst.rays_traced == cst.rays_traced
+        ctx.close()
+
+
 def test_error_codes_through_the_abi(gpu_ctx, cornell):
     lib = gpu_ctx.lib
     h = C.c_void_p()
