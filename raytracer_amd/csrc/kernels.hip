@@ -243,41 +243,27 @@ __device__ __forceinline__ void sphere_test(const float4 *__restrict__ prim, uin
     sphere_test(prim[0], slot, o, d, tmin, best);
 }
 
-// BvhNode::hit (src/bvh.rs:295-317) as a stackless pre-order walk.  `best.t` plays the role of the
-// shrinking `hit_range.max`: the reference hands the right sibling max = the left hit's distance, and every
-// later node therefore sees the closest distance found so far in visiting order.
-// `nodes` / `prims` may point at HBM or at a copy of the tables in LDS.
-// LDS: `nodes` is the LDS copy, whose skip links are byte offsets.
-template <bool COUNT, bool LDS>
-__device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ prims,
-                                            uint32_t n_nodes, V3 o, V3 d, float tmin, float tmax,
-                                            uint32_t &n_nodes_visited, uint32_t &n_tri, uint32_t &n_sph) {
+// BvhNode::hit (src/bvh.rs:295-317) as a stackless pre-order walk over the node table in device memory.  `best.t`
+// plays the role of the shrinking `hit_range.max`: the reference hands the right sibling max = the left hit's
+// distance, and every later node therefore sees the closest distance found so far in visiting order.
+__device__ __forceinline__ Closest traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ prims, uint32_t n_nodes, V3 o,
+                                            V3 d, float tmin, float tmax) {
     const Slabs slabs = make_slabs(o, d);
     Closest best{tmax, kMissSlot, 0.0f, 0.0f};
-    // On the LDS copy the walk runs on byte offsets (32 per node; the copy's skip links are stored that way),
-    // which is the address the LDS read wants.
-    constexpr uint32_t kStep = LDS ? 32u : 1u;
     tmin = in_vgpr(tmin);
     uint32_t idx = 0;
-    const uint32_t end = n_nodes * kStep;
-    while (idx < end) {
-        const float4 *node = LDS ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + idx) : nodes + 2 * idx;
-        float4 nlo = node[0];
-        float4 nhi = node[1];
-        if (COUNT) ++n_nodes_visited;
-        bool hit = box_hit(nlo, nhi, slabs, tmin, best.t);
-        uint32_t leaf = f2u(nhi.w);
+    while (idx < n_nodes) {
+        const float4 nlo = nodes[2 * idx], nhi = nodes[2 * idx + 1];
+        const bool hit = box_hit(nlo, nhi, slabs, tmin, best.t);
+        const uint32_t leaf = f2u(nhi.w);
         if (hit && leaf != kInterior) {
-            uint32_t slot = leaf & ~kSphereBit;
-            if (leaf & kSphereBit) {
-                if (COUNT) ++n_sph;
+            const uint32_t slot = leaf & ~kSphereBit;
+            if (leaf & kSphereBit)
                 sphere_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
-            } else {
-                if (COUNT) ++n_tri;
+            else
                 tri_test(prims + 3 * (size_t)slot, slot, o, d, tmin, best);
-            }
         }
-        idx = hit ? idx + kStep : f2u(nhi.z);
+        idx = hit ? idx + 1u : f2u(nhi.z);
     }
     return best;
 }
@@ -1555,8 +1541,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HAS_MIX 
                 if constexpr (LDS_SCENE) {
                     best = traverse_sorted(sorted_nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far);
                 } else {
-                    uint32_t c0 = 0, c1 = 0, c2 = 0;
-                    best = traverse<false, false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+                    best = traverse(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far);
                 }
             }
             alive = shade_path<NEED_UV, HAS_MIX>(sc, root_lo, root_hi, prims, P, st, slot, o, d, beta, k, flags, depth, s_local, pixel, best);
@@ -1605,8 +1590,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((THREAD
         } else if constexpr (LDS_SCENE) {
             return traverse_sorted(sorted_nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far);
         } else {
-            uint32_t c0 = 0, c1 = 0, c2 = 0;
-            return traverse<false, false>(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far, c0, c1, c2);
+            return traverse(nodes, prims, sc.n_nodes, o, d, P.z_near, P.z_far);
         }
     };
     if (threadIdx.x == 0) {
