@@ -427,6 +427,50 @@ def test_lanes_pipeline_variants(cornell, teapot, monkeypatch, traversal, first)
     ctx.close()
 
 
+@pytest.mark.parametrize("knobs", [
+    {"RT_LANES_TRAVERSAL": "walk", "RT_WALK_TOP_KB": "0"},
+    {"RT_LANES_TRAVERSAL": "walk", "RT_WALK_TOP_KB": "1", "RT_WALK_THREADS": "256", "RT_WALK_BLOCKS_PER_CU": "4"},
+    {"RT_LANES_TRAVERSAL": "walk", "RT_WALK_TOP_KB": "5", "RT_WALK_THREADS": "512", "RT_WALK_BLOCKS_PER_CU": "3"},
+    {"RT_LANES_TRAVERSAL": "walk", "RT_WALK_TOP_KB": "150", "RT_WALK_THREADS": "1024", "RT_WALK_BLOCKS_PER_CU": "1"},
+    {"RT_LANES_TRAVERSAL": "chain", "RT_CHAIN_TOP_RECORDS": "0"},
+    {"RT_LANES_TRAVERSAL": "chain", "RT_CHAIN_TOP_RECORDS": "1", "RT_CHAIN_THREADS": "256"},
+    {"RT_LANES_TRAVERSAL": "chain", "RT_CHAIN_TOP_RECORDS": "7", "RT_CHAIN_THREADS": "512"},
+    {"RT_LANES_TRAVERSAL": "chain", "RT_CHAIN_TOP_RECORDS": "1200", "RT_CHAIN_THREADS": "256"},
+], ids=lambda k: "-".join(v for v in k.values()))
+def test_lds_prefix_sizes_and_block_shapes(cornell, teapot, monkeypatch, knobs):
+    """The part of the tree kept in LDS is a performance choice and must never show in a result: the walk table's
+    level-ordered prefix from none at all over one that a walk leaves and re-enters at almost every step (1 KB = 32
+    nodes) to one that holds whole trees, and the chain records' LDS copies from none over the root alone to more than
+    most trees have; each with a block shape other than the default.  Closest hits, sums and ray counts equal the
+    oracle's bit for bit on Cornell, the teapot, a 60 000-triangle soup and three random scenes."""
+    from helpers import random_scene
+
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    ctx = Context(0)
+    ctx.set_pipeline(F.RT_PIPELINE_LANES)
+    lit, lit_cam = lit_teapot(teapot)
+    soup, soup_cam = triangle_soup(60000, emissive_fraction=0.02)
+    cases = [(cornell, None, (-1, -1, -1), (1, 1, 1)), (lit, lit_cam, (-35, -20, -22), (35, 18, 22)),
+             (soup, soup_cam, (-1, -1, -1), (1, 1, 1))]
+    cases += [random_scene(seed) + ((-2.5, -2.5, -2.5), (2.5, 2.5, 2.5)) for seed in (3, 31, 40)]
+    for k, (desc, cs, lo, hi) in enumerate(cases):
+        g, o = both(ctx, desc)
+        rays = random_rays(20011, lo, hi, seed=900 + k, axis_aligned_fraction=0.2)
+        got, _ = g.trace_closest(rays, 1e-3, np.inf)
+        want, _ = o.trace_closest(rays, 1e-3, np.inf)
+        assert_hits_equal(got, want)
+        cam = camera_from_settings(cs or desc.camera(0), 96, 64)
+        rs = RenderSettings(96, 64, 0, 10, 4, mode=F.RT_MODE_LINEAR_MEAN, seed=300 + k, background_color=(0.2, 0.3, 0.4))
+        r = Renderer(cam, g, rs)
+        gpu = r.render_sums()
+        cpu, cst = o.render(cam, rs, threads=16)
+        assert_images_equal(gpu, cpu)
+        assert r.last_stats.rays_traced == cst.rays_traced and r.last_stats.pipeline == F.RT_PIPELINE_LANES
+        g.close()
+    ctx.close()
+
+
 def test_mid_size_scene_uses_the_shared_lds_copy(gpu_ctx):
     """Scene tables whose LDS copy (48 bytes per node and per primitive) takes between 40 and 150 KB (here 1000
     triangles = 141 KB, and the 485 spheres = 68 KB) are staged in LDS once per 1024-thread block by the default
