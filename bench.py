@@ -116,6 +116,25 @@ def committed_profile(name, kernel_hint, rays_per_launch):
     return p, os.path.relpath(path, ROOT)
 
 
+def committed_kernel_stats(name, kernels):
+    """Average duration (ms) of the render kernels `kernels` ("a + b" when a launch is two kernels) in the committed
+    `rocprofv3 --kernel-trace --stats` summary of this leg: of the default bench command for Cornell, of the leg's
+    own launches otherwise.  (None, None) without a summary or when a kernel is not in it."""
+    import csv
+
+    path = os.path.join(ROOT, "profiles", f"r03_{'bench' if name == 'cornell' else name}_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None, None
+    rows = list(csv.DictReader(open(path)))
+    total = 0.0
+    for k in kernels.split(" + "):
+        hit = [r for r in rows if r["Name"].startswith(k + "(")]
+        if len(hit) != 1:
+            return None, None
+        total += float(hit[0]["AverageNs"]) * 1e-6
+    return total, os.path.relpath(path, ROOT)
+
+
 def run_leg(name, device, launches, warmup=1, width=None, height=None, want_counts=True):
     """Times `launches` identical launches of one configuration (samples [0, spp) of every pixel) with HIP events on
     the context's stream, and counts box / primitive tests per ray with the instrumented kernels."""
@@ -219,7 +238,11 @@ def roofline_of(name, leg):
                   "hbm_traffic_gbs": traffic / secs / 1e9, "hbm_traffic_frac_of_peak": traffic / secs / 1e9 / HBM_PEAK_GBS,
                   "valu_wave_instructions_per_ray": d["valu_wave_instructions"], "lane_utilisation": prof["lane_utilisation"],
                   "l2_requests_per_ray": d.get("l2_read_requests"), "l2_misses_per_ray": d.get("hbm_read_requests"),
-                  "rocprof_avg_launch_ms": prof.get("avg_dispatch_ms")})
+                  # the kernel-trace run beside the counter passes: three launches from a cold start (for a launch as
+                  # short as Cornell's the clocks are still ramping; the bench command's own summary is below)
+                  "avg_launch_ms_in_the_profiled_leg_run": prof.get("avg_dispatch_ms")})
+        stats_ms, stats_path = committed_kernel_stats(name, prof["kernel"])
+        r.update({"rocprof_kernel_stats_avg_ms": stats_ms, "rocprof_kernel_stats": stats_path})
     if hbm_bound:
         r.update({"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
                   "traffic": traffic})
